@@ -1,0 +1,175 @@
+/* ldmseg_hip.h - C ABI of libldmseg_hip.so, the MI355X (gfx950) implementation of
+ * the LDMSeg denoising path.
+ *
+ * The reference (segments-ai/latent-diffusion-segmentation) has no FFI layer: the
+ * seam is the Python call surface TrainerDiffusion uses.  Each entry point below
+ * names the reference interface it stands behind (paths relative to the
+ * reference root); INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions
+ *   - every pointer named *dev* / tensor argument is a DEVICE pointer on the
+ *     handle's GPU; boundary tensors are fp32 NCHW contiguous (the reference's
+ *     layout); timesteps are int64.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls
+ *     only enqueue work; they never synchronise the stream or the device.
+ *   - return 0 on success, negative LDMSEG_E_* on failure; ldmseg_last_error()
+ *     returns a thread-local message.  No C++ exception crosses the boundary.
+ *   - the library owns handles, repacked weights and workspaces; the caller owns
+ *     every tensor it passes and keeps it alive until the stream work is done.
+ *     Weights are copied/repacked at create time.
+ *   - a handle is bound to one device and is not thread-safe (one process per GPU,
+ *     like tools/main_ldm.py:69 mp.spawn).
+ */
+#ifndef LDMSEG_HIP_H_
+#define LDMSEG_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LDMSEG_OK 0
+#define LDMSEG_E_ARG (-1)      /* bad argument / unsupported option */
+#define LDMSEG_E_SHAPE (-2)    /* shape not supported by the kernels */
+#define LDMSEG_E_HIP (-3)      /* HIP runtime error (message has the hipError string) */
+#define LDMSEG_E_WEIGHT (-4)   /* missing / mis-sized state-dict entry */
+#define LDMSEG_E_ARCH (-5)     /* device is not gfx950 */
+#define LDMSEG_E_OOM (-6)
+
+#define LDMSEG_F32 0           /* fp32 storage, exact-f32 MFMA: the parity mode (1e-3 vs torch-CPU) */
+#define LDMSEG_BF16 1          /* bf16 storage + bf16 MFMA, fp32 accumulate/statistics: the perf mode */
+
+#define LDMSEG_PRED_EPSILON 0
+#define LDMSEG_PRED_SAMPLE 1
+#define LDMSEG_PRED_V 2
+
+typedef struct ldmseg_unet ldmseg_unet;  /* opaque */
+typedef struct ldmseg_vae ldmseg_vae;    /* opaque */
+
+/* ---- UNet: ldmseg/models/unet.py::UNet (UNet2DConditionModel, SD-1.x topology) ---------- */
+typedef struct {
+  int32_t in_channels;      /* 8 | 12 after UNet.modify_encoder (unet.py:178-233); 4 = vanilla */
+  int32_t cross_attention;  /* 0: attn2/norm2 removed (unet.py:83-105, base.yaml:71). 1 is rejected (E_ARG) */
+  int32_t compute_dtype;    /* LDMSEG_F32 | LDMSEG_BF16 */
+  int32_t device;           /* HIP device ordinal */
+} ldmseg_unet_cfg;
+
+/* Build a UNet from a state dict in the reference's key layout (the `unet` entry of
+ * ldmseg.pt, trainers_ldm_cond.py:1791-1814; keys = SURVEY.md App. A).  `names[i]` is
+ * the key, `dev_ptrs[i]` an fp32 device tensor in torch layout with `numels[i]`
+ * elements.  Unknown keys (e.g. the duplicate `new_conv.*`, unet.py:182,233) are
+ * ignored; a missing or mis-sized required key fails with LDMSEG_E_WEIGHT.
+ * Replaces: UNet.from_pretrained + remove_cross_attention + modify_encoder +
+ * load_state_dict (tools/main_ldm.py:146-168, trainers_ldm_cond.py:1863-1891). */
+int ldmseg_unet_create(const ldmseg_unet_cfg* cfg, int n_weights, const char* const* names,
+                       const void* const* dev_ptrs, const int64_t* numels, ldmseg_unet** out);
+void ldmseg_unet_destroy(ldmseg_unet* h);
+
+/* UNet.forward(sample, timestep, encoder_hidden_states=None).sample  (unet.py:281-436).
+ * x: [B, in_channels, L, L] fp32; out: [B, 4, L, L] fp32.  The timestep is read from
+ * `t_dev` (int64 on device, `t_count` = 1 -> broadcast like timestep.expand(B), or B)
+ * so a GPU-resident scheduler.timesteps[i] needs no D2H sync; if t_dev is NULL,
+ * `t_host` is used.  L must be a multiple of 8. */
+int ldmseg_unet_forward(ldmseg_unet* h, const float* x, const int64_t* t_dev, int t_count, int64_t t_host,
+                        int B, int L, float* out, void* stream);
+/* Same forward but the input is given as its channel-concat parts
+ * (torch.cat([latents, rgb_latents, condition], dim=1), trainers_ldm_cond.py:1128-1138);
+ * `cond` may be NULL when in_channels == 8. */
+int ldmseg_unet_forward_parts(ldmseg_unet* h, const float* latents, const float* rgb_latents, const float* cond,
+                              const int64_t* t_dev, int t_count, int64_t t_host, int B, int L, float* out,
+                              void* stream);
+/* bytes of device workspace a forward at (B, L) needs (allocated lazily, grown never shrunk) */
+size_t ldmseg_unet_workspace_bytes(const ldmseg_unet* h, int B, int L);
+/* number of parameters held (815,556,484 for the 12-channel default) */
+int64_t ldmseg_unet_num_params(const ldmseg_unet* h);
+
+/* ---- seg-VAE: ldmseg/models/vae.py::GeneralVAESeg (gaussian, num_mid_blocks=0) ------------ */
+typedef struct {
+  int32_t in_channels;      /* 7  (bit maps, base.yaml:15) */
+  int32_t int_channels;     /* 256 */
+  int32_t out_channels;     /* 128 */
+  int32_t latent_channels;  /* 4 */
+  int32_t num_latents;      /* 2 (mean, logvar) */
+  int32_t num_upscalers;    /* 2 */
+  int32_t upscale_channels; /* 256 */
+  int32_t norm_num_groups;  /* 32 */
+  int32_t block_out_channels[4]; /* 32,64,128,256 */
+  int32_t compute_dtype;
+  int32_t device;
+} ldmseg_vae_cfg;
+
+/* keys: encoder.{0,2,3,5,6,8,9,11,13,15}.{weight,bias}, decoder.{0,2,3,5,6,8,10}.{weight,bias}
+ * (vae.py:123-244; the AE checkpoint's 'module.' prefix is stripped by the caller, vae.py:116-121) */
+int ldmseg_vae_create(const ldmseg_vae_cfg* cfg, int n_weights, const char* const* names,
+                      const void* const* dev_ptrs, const int64_t* numels, ldmseg_vae** out);
+void ldmseg_vae_destroy(ldmseg_vae* h);
+/* GeneralVAESeg.decode(z, interpolate) (vae.py:267-271): z [B,4,L,L] -> logits
+ * [B,128,4L,4L] (interpolate=0) or [B,128,8L,8L] (bilinear x2, align_corners=False).
+ * `z_scale` multiplies z first (decode_latents' 1/scaling_factor, trainers_ldm_cond.py:421). */
+int ldmseg_vae_decode(ldmseg_vae* h, const float* z, float z_scale, int B, int L, int interpolate, float* logits,
+                      void* stream);
+/* GeneralVAESeg.encode(x) (vae.py:252-265): x [B,7,H,W] (H=W multiple of 8), moments
+ * [B,8,H/8,W/8] = (mean | logvar) before the clamp.  x is used as x*in_mul+in_add
+ * (encode_inputs' 2x-1, trainers_ldm_cond.py:369). */
+int ldmseg_vae_encode(ldmseg_vae* h, const float* x, float in_mul, float in_add, int B, int H, float* moments,
+                      void* stream);
+/* DiagonalGaussianDistribution.mode()/.sample() (vae.py:370-413) on `moments`:
+ * out[B,4,l,l] = (mean + exp(0.5*clamp(logvar,-30,20))*noise) * out_scale; noise NULL -> mode(). */
+int ldmseg_vae_posterior(const float* moments, const float* noise, float out_scale, int B, int l, float* out,
+                         void* stream);
+int64_t ldmseg_vae_num_params(const ldmseg_vae* h);
+
+/* ---- scheduler: ldmseg/schedulers/ddim_scheduler.py --------------------------------------- */
+/* DDIMNoiseScheduler.step (:218-269), elementwise over n floats.  The four coefficients are
+ * the 0-d fp32 values the reference computes on the host (alpha_prod_t**0.5, ...); every
+ * product/sum is rounded separately, so outputs equal the torch result bit for bit.
+ * prev or x0 may be NULL. */
+int ldmseg_ddim_step(const float* model_output, const float* sample, float sqrt_alpha_t, float sqrt_beta_t,
+                     float sqrt_alpha_prev, float sqrt_beta_prev, int prediction_type, int clip_sample,
+                     float clip_sample_range, int use_clipped_model_output, float* prev_sample,
+                     float* pred_original_sample, size_t n, void* stream);
+/* add_noise (:155-187) / remove_noise (:190-216) with per-sample int64 timesteps [B] and the
+ * fp32 alphas_cumprod table on device. */
+int ldmseg_add_noise(const float* original, const float* noise, const int64_t* timesteps_dev,
+                     const float* alphas_cumprod_dev, float scale, float* out, int B, size_t per_sample,
+                     void* stream);
+int ldmseg_remove_noise(const float* noisy, const float* noise, const int64_t* timesteps_dev,
+                        const float* alphas_cumprod_dev, float scale, float* out, int B, size_t per_sample,
+                        void* stream);
+
+/* ---- sampler: TrainerDiffusion.sample (trainers_ldm_cond.py:1045-1170) -------------------- */
+typedef struct {
+  int32_t n_steps;               /* len(scheduler.timesteps) */
+  const int64_t* timesteps;      /* host, descending */
+  const float* coef;             /* host [n_steps][4]: sqrt_a_t, sqrt_b_t, sqrt_a_prev, sqrt_b_prev */
+  int32_t prediction_type, clip_sample, self_condition;
+  float clip_sample_range;
+  /* build-defined mask inpainting (absent from the reference): all NULL = off */
+  const uint8_t* known_dev;      /* [B,1,L,L] 1 = latent given */
+  const float* z0_dev;           /* [B,4,L,L] scaled known latents */
+  const float* noise_dev;        /* [B,4,L,L] the fixed noise draw */
+  const float* paste_coef;       /* host [n_steps][2]: sqrt_a, sqrt_b of the NEXT timestep (last: 1,0) */
+} ldmseg_sample_cfg;
+/* Runs the whole loop on `stream`: latents [B,4,L,L] holds the initial noise on entry and the
+ * final latents on exit (last step = pred_original_sample, :1154-1156).  If all_latents is
+ * non-NULL it receives every step's latents [n_steps][B,4,L,L] (return_all_latents). */
+int ldmseg_sample_loop(ldmseg_unet* h, const ldmseg_sample_cfg* cfg, float* latents, const float* rgb_latents,
+                       int B, int L, float* all_latents, void* stream);
+
+/* ---- diagnostics --------------------------------------------------------------------------- */
+const char* ldmseg_last_error(void);
+const char* ldmseg_version(void);
+/* Kernel-family timing (HIP events on the launch stream).  enable=1 records an event pair
+ * around every launch of the family (0 igemm, 1 attention, 2 groupnorm, 3 layernorm, 4 other);
+ * ldmseg_profile_read synchronises the recorded events and returns launches / total ms /
+ * algorithmic FLOPs and bytes since the last reset. */
+int ldmseg_profile_enable(int enable);
+int ldmseg_profile_read(int family, int64_t* launches, double* total_ms, double* flops, double* bytes);
+int ldmseg_profile_reset(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LDMSEG_HIP_H_ */

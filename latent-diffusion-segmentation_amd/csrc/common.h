@@ -1,0 +1,98 @@
+// Shared device/host helpers for the LDMSeg gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+
+namespace ldmseg {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short bf16_t;  // raw bf16 bits
+
+// One LDS/global "chunk" is 16 bytes: 8 bf16 or 4 f32.
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static constexpr int kPerChunk = 4;
+  static constexpr int kDType = DT_F32;
+};
+template <> struct Elem<bf16_t> {
+  static constexpr int kPerChunk = 8;
+  static constexpr int kDType = DT_BF16;
+};
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) {
+  return __builtin_bit_cast(float, (uint32_t)v << 16);
+}
+// round-to-nearest-even, NaN kept quiet
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  uint32_t u = __builtin_bit_cast(uint32_t, f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return bf16_to_f32(v); }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return f32_to_bf16(v); }
+
+// Unpack a 16-byte chunk into Elem<T>::kPerChunk floats and back.
+template <typename T> struct Chunk;
+template <> struct Chunk<float> {
+  static constexpr int N = 4;
+  __device__ __forceinline__ static void unpack(const uint4& c, float* f) {
+    f[0] = __builtin_bit_cast(float, c.x); f[1] = __builtin_bit_cast(float, c.y);
+    f[2] = __builtin_bit_cast(float, c.z); f[3] = __builtin_bit_cast(float, c.w);
+  }
+  __device__ __forceinline__ static uint4 pack(const float* f) {
+    return make_uint4(__builtin_bit_cast(uint32_t, f[0]), __builtin_bit_cast(uint32_t, f[1]),
+                      __builtin_bit_cast(uint32_t, f[2]), __builtin_bit_cast(uint32_t, f[3]));
+  }
+};
+template <> struct Chunk<bf16_t> {
+  static constexpr int N = 8;
+  __device__ __forceinline__ static void unpack(const uint4& c, float* f) {
+    f[0] = __builtin_bit_cast(float, c.x << 16); f[1] = __builtin_bit_cast(float, c.x & 0xffff0000u);
+    f[2] = __builtin_bit_cast(float, c.y << 16); f[3] = __builtin_bit_cast(float, c.y & 0xffff0000u);
+    f[4] = __builtin_bit_cast(float, c.z << 16); f[5] = __builtin_bit_cast(float, c.z & 0xffff0000u);
+    f[6] = __builtin_bit_cast(float, c.w << 16); f[7] = __builtin_bit_cast(float, c.w & 0xffff0000u);
+  }
+  __device__ __forceinline__ static uint4 pack(const float* f) {
+    return make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]),
+                      pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
+  }
+};
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// exact (erf) GELU, matching torch.nn.functional.gelu default
+__device__ __forceinline__ float gelu_erf_f(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+// One MFMA "k-group" = 64 bytes of K per operand row (4 lane-groups x 16 B):
+// bf16: one v_mfma_f32_16x16x32_bf16; f32: four v_mfma_f32_16x16x4_f32, lane
+// group g supplying k = 4*g + t in the t-th instruction (any K permutation is
+// legal as long as both operands use the same one).
+template <typename T>
+__device__ __forceinline__ void mma_kgroup(const uint4& a, const uint4& b, f32x4& acc);
+template <>
+__device__ __forceinline__ void mma_kgroup<bf16_t>(const uint4& a, const uint4& b, f32x4& acc) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ void mma_kgroup<float>(const uint4& a, const uint4& b, f32x4& acc) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.x), __builtin_bit_cast(float, b.x), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.y), __builtin_bit_cast(float, b.y), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.z), __builtin_bit_cast(float, b.z), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.w), __builtin_bit_cast(float, b.w), acc, 0, 0, 0);
+}
+
+}  // namespace ldmseg

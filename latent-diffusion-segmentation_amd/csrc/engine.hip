@@ -1,0 +1,1070 @@
+// Host runtime of libldmseg_hip.so: weight repacking, workspace planning, the UNet /
+// seg-VAE executors, the DDIM sampling loop and the C ABI (include/ldmseg_hip.h).
+//
+// Layout in HBM: activations NHWC [B, H*W, C] in the compute dtype;
+// conv/linear weights [N][K] with K = (tap, channel) so one 128-B line of a weight row
+// is one K tile; norm parameters, biases and the time-embedding MLP stay fp32.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/ldmseg_hip.h"
+#include "kernels.h"
+
+using namespace ldmseg;
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t e__ = (expr);                                                                  \
+    if (e__ != hipSuccess)                                                                    \
+      return fail(LDMSEG_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));          \
+  } while (0)
+#define TRY(expr)                                                                             \
+  do {                                                                                        \
+    int r__ = (expr);                                                                         \
+    if (r__ != 0) {                                                                           \
+      if (g_err.empty())                                                                      \
+        g_err = std::string(#expr) + " failed (" + std::to_string(r__) + ")" +                \
+                (r__ == -3 ? std::string(": ") + hipGetErrorString(hipGetLastError()) : ""); \
+      return r__;                                                                             \
+    }                                                                                         \
+  } while (0)
+
+inline size_t rup(size_t v, size_t a) { return (v + a - 1) / a * a; }
+inline size_t esize(int dt) { return dt == DT_BF16 ? 2 : 4; }
+inline int bke(int dt) { return dt == DT_BF16 ? 64 : 32; }  // channels per 128-B K tile
+
+// ------------------------------------------------------------------ profiling
+struct ProfFamily {
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+  int64_t launches = 0;
+  double flops = 0, bytes = 0;
+};
+struct Profiler {
+  bool on = false;
+  ProfFamily fam[5];
+  std::vector<hipEvent_t> pool;
+  hipEvent_t get() {
+    if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+  }
+} g_prof;
+
+struct ProfScope {
+  int f; hipStream_t s; hipEvent_t a{}, b{}; bool on;
+  ProfScope(int family, hipStream_t st, double flops, double bytes, bool dry) : f(family), s(st) {
+    on = g_prof.on && !dry;
+    if (on) {
+      a = g_prof.get(); b = g_prof.get();
+      (void)hipEventRecord(a, s);
+      g_prof.fam[f].launches++;
+      g_prof.fam[f].flops += flops;
+      g_prof.fam[f].bytes += bytes;
+    }
+  }
+  ~ProfScope() {
+    if (on) { (void)hipEventRecord(b, s); g_prof.fam[f].ev.emplace_back(a, b); }
+  }
+};
+
+// ------------------------------------------------------------------ device memory
+struct DeviceArena {  // persistent parameters: chunked bump allocator
+  std::vector<void*> chunks;
+  char* cur = nullptr;
+  size_t left = 0;
+  size_t total = 0;
+  int alloc(void** out, size_t bytes) {
+    bytes = rup(bytes, 256);
+    if (bytes > left) {
+      const size_t chunk = bytes > ((size_t)256 << 20) ? bytes : ((size_t)256 << 20);
+      void* p = nullptr;
+      if (hipMalloc(&p, chunk) != hipSuccess) return fail(LDMSEG_E_OOM, "hipMalloc of parameter chunk failed");
+      chunks.push_back(p);
+      cur = (char*)p;
+      left = chunk;
+      total += chunk;
+    }
+    *out = cur;
+    cur += bytes;
+    left -= bytes;
+    return 0;
+  }
+  void release() {
+    for (void* p : chunks) (void)hipFree(p);
+    chunks.clear();
+    cur = nullptr;
+    left = 0;
+  }
+};
+
+struct Workspace {  // per-forward activations: persist (bump) + scratch (stack)
+  char* base = nullptr;
+  size_t cap = 0;
+  size_t persist_top = 0, scratch_top = 0, scratch_base = 0;
+  size_t persist_peak = 0, scratch_peak = 0;
+  bool dry = false;
+  void begin(bool dry_, size_t scratch_base_) {
+    dry = dry_;
+    persist_top = 0;
+    scratch_base = scratch_base_;
+    scratch_top = 0;
+    persist_peak = scratch_peak = 0;
+  }
+  void* persist(size_t bytes) {
+    const size_t off = persist_top;
+    persist_top += rup(bytes, 256);
+    if (persist_top > persist_peak) persist_peak = persist_top;
+    return dry ? (void*)(uintptr_t)(0x1000 + off) : base + off;
+  }
+  void* scratch(size_t bytes) {
+    const size_t off = scratch_top;
+    scratch_top += rup(bytes, 256);
+    if (scratch_top > scratch_peak) scratch_peak = scratch_top;
+    return dry ? (void*)(uintptr_t)(0x1000 + off) : base + scratch_base + off;
+  }
+  size_t mark() const { return scratch_top; }
+  void reset(size_t m) { scratch_top = m; }
+};
+
+struct WeightMap {
+  std::unordered_map<std::string, std::pair<const float*, int64_t>> m;
+  int get(const std::string& key, int64_t numel, const float** out) const {
+    auto it = m.find(key);
+    if (it == m.end()) return fail(LDMSEG_E_WEIGHT, "missing state-dict key: " + key);
+    if (it->second.second != numel)
+      return fail(LDMSEG_E_WEIGHT, "state-dict key " + key + " has " + std::to_string(it->second.second) +
+                                       " elements, expected " + std::to_string(numel));
+    *out = it->second.first;
+    return 0;
+  }
+};
+
+struct ConvW {
+  void* w = nullptr;      // [N][taps*cin_pad]
+  float* bias = nullptr;  // [N]
+  int N = 0, n_valid = 0, cin_pad = 0, taps = 1, cout = 0;
+};
+struct NormW { float* g = nullptr; float* b = nullptr; int C = 0; };
+
+struct Builder {
+  DeviceArena* arena;
+  const WeightMap* wm;
+  int dt;
+  hipStream_t s;
+  int64_t nparams = 0;
+  std::vector<void*> temps;
+
+  int f32_copy(const std::string& key, int64_t n, float** out, int64_t pad_to = 0) {
+    const float* src;
+    TRY(wm->get(key, n, &src));
+    const int64_t tot = pad_to > n ? pad_to : n;
+    void* p;
+    TRY(arena->alloc(&p, tot * sizeof(float)));
+    if (tot > n) HIP_TRY(hipMemsetAsync(p, 0, tot * sizeof(float), s));
+    HIP_TRY(hipMemcpyAsync(p, src, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    *out = (float*)p;
+    nparams += n;
+    return 0;
+  }
+  int norm(const std::string& prefix, int C, NormW* out) {
+    out->C = C;
+    TRY(f32_copy(prefix + ".weight", C, &out->g));
+    TRY(f32_copy(prefix + ".bias", C, &out->b));
+    return 0;
+  }
+  // Conv2d / Linear: OIHW -> [Npad][k*k][cin_pad]; n_store >= Co forces explicit zero output channels
+  int conv(const std::string& prefix, int Co, int Ci, int k, int cin_pad, ConvW* out, bool has_bias = true,
+           int n_store = 0, int epi = EPI_STORE) {
+    const float* w;
+    TRY(wm->get(prefix + ".weight", (int64_t)Co * Ci * k * k, &w));
+    const int nreal = n_store > Co ? n_store : Co;
+    const int bn = igemm_pick_bn(nreal, epi);
+    const int Npad = (int)rup(nreal, bn);
+    out->N = Npad;
+    out->n_valid = nreal;
+    out->cin_pad = cin_pad;
+    out->taps = k * k;
+    out->cout = Co;
+    TRY(arena->alloc(&out->w, (size_t)Npad * k * k * cin_pad * esize(dt)));
+    TRY(launch_repack_conv(w, out->w, Co, Ci, k, k, Npad, cin_pad, dt, s));
+    nparams += (int64_t)Co * Ci * k * k;
+    if (has_bias) TRY(f32_copy(prefix + ".bias", Co, &out->bias, Npad));
+    else {
+      void* p;
+      TRY(arena->alloc(&p, Npad * sizeof(float)));
+      HIP_TRY(hipMemsetAsync(p, 0, Npad * sizeof(float), s));
+      out->bias = (float*)p;
+    }
+    return 0;
+  }
+  int upload_ints(const std::vector<int>& v, int** dev) {
+    void* p;
+    HIP_TRY(hipMalloc(&p, v.size() * sizeof(int)));
+    temps.push_back(p);
+    HIP_TRY(hipMemcpyAsync(p, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice, s));
+    *dev = (int*)p;
+    return 0;
+  }
+  int finish() {
+    HIP_TRY(hipStreamSynchronize(s));
+    for (void* p : temps) (void)hipFree(p);
+    temps.clear();
+    return 0;
+  }
+};
+
+// ------------------------------------------------------------------ executor helpers
+struct Act {
+  void* p = nullptr;
+  int C = 0, H = 0, W = 0;
+};
+
+struct Exec {
+  Workspace* ws;
+  int dt;
+  int B;
+  hipStream_t s;
+  bool dry() const { return ws->dry; }
+
+  Act new_act(int C, int H, int W, bool persist) {
+    Act a;
+    a.C = C; a.H = H; a.W = W;
+    const size_t bytes = (size_t)B * H * W * C * esize(dt);
+    a.p = persist ? ws->persist(bytes) : ws->scratch(bytes);
+    return a;
+  }
+
+  int igemm(IgemmParams& p) {
+    const double flops = 2.0 * p.M * (double)p.n_valid * p.taps * (p.C0 + p.C1);
+    const double bytes = ((double)p.M * (p.C0 + p.C1) + (double)p.N * p.taps * (p.C0 + p.C1) + (double)p.M * p.n_valid) * esize(dt);
+    ProfScope ps(0, s, flops, bytes, dry());
+    if (dry()) return 0;
+    return launch_igemm(p, dt, s);
+  }
+
+  // conv3x3 / 1x1 over NHWC `x` (optionally channel-concatenated with `x2`)
+  int conv(const ConvW& w, const Act& x, const Act* x2, Act* out, int stride, int up, bool persist,
+           const float* rowbias, int rb_stride, const Act* resid, int silu = 0) {
+    const int ctot = x.C + (x2 ? x2->C : 0);
+    if (ctot != w.cin_pad) return fail(LDMSEG_E_SHAPE, "conv: channel mismatch");
+    const int Hl = up ? 2 * x.H : x.H, Wl = up ? 2 * x.W : x.W;
+    const int Ho = (w.taps == 9 && stride == 2) ? (Hl - 1) / 2 + 1 : Hl;
+    const int Wo = (w.taps == 9 && stride == 2) ? (Wl - 1) / 2 + 1 : Wl;
+    *out = new_act(w.n_valid, Ho, Wo, persist);
+    IgemmParams p;
+    p.src0 = x.p; p.C0 = x.C;
+    if (x2) { p.src1 = x2->p; p.C1 = x2->C; }
+    p.B = B; p.Hi = x.H; p.Wi = x.W; p.Ho = Ho; p.Wo = Wo;
+    p.taps = w.taps; p.stride = stride; p.up = up;
+    p.M = B * Ho * Wo; p.N = w.N; p.n_valid = w.n_valid;
+    p.W = w.w; p.bias = w.bias;
+    p.rowbias = rowbias; p.rb_stride = rb_stride;
+    if (resid) { p.resid = resid->p; p.ldr = resid->C; }
+    p.out = out->p; p.ldo = w.n_valid;
+    p.epi = EPI_STORE; p.silu = silu;
+    return igemm(p);
+  }
+
+  int groupnorm(const NormW& n, const Act& x, const Act* x2, float eps, int silu, Act* out) {
+    const int ctot = x.C + (x2 ? x2->C : 0);
+    if (ctot != n.C) return fail(LDMSEG_E_SHAPE, "groupnorm: channel mismatch");
+    *out = new_act(ctot, x.H, x.W, false);
+    GNParams g;
+    g.src0 = x.p; g.C0 = x.C;
+    if (x2) { g.src1 = x2->p; g.C1 = x2->C; }
+    g.B = B; g.HW = x.H * x.W; g.groups = 32;
+    g.gamma = n.g; g.beta = n.b; g.eps = eps; g.silu = silu;
+    g.out = out->p;
+    g.nchunk = gn_nchunk(B, g.HW);
+    g.partial = (float*)ws->scratch((size_t)B * g.nchunk * 32 * 2 * sizeof(float));
+    const double bytes = 3.0 * B * g.HW * ctot * esize(dt);
+    ProfScope ps(2, s, 0, bytes, dry());
+    if (dry()) return 0;
+    return launch_groupnorm(g, dt, s);
+  }
+
+  int layernorm(const NormW& n, const Act& x, float eps, int silu, Act* out, bool inplace = false) {
+    *out = inplace ? x : new_act(x.C, x.H, x.W, false);
+    const int M = B * x.H * x.W;
+    ProfScope ps(3, s, 0, 2.0 * M * x.C * esize(dt), dry());
+    if (dry()) return 0;
+    return launch_layernorm(x.p, out->p, n.g, n.b, M, x.C, eps, silu, dt, s);
+  }
+};
+
+// ------------------------------------------------------------------ UNet
+constexpr int kBlockOut[4] = {320, 640, 1280, 1280};
+constexpr int kTimeDim = 1280;
+
+struct ResnetW {
+  NormW norm1, norm2;
+  ConvW conv1, conv2, shortcut;
+  bool has_shortcut = false;
+  int cin = 0, cout = 0, temb_off = 0;
+};
+struct TransformerW {
+  int C = 0;
+  NormW norm, ln1, ln3;
+  ConvW proj_in, qkv, attn_out, ff1, ff2, proj_out;
+};
+
+}  // namespace
+
+struct ldmseg_unet {
+  ldmseg_unet_cfg cfg{};
+  int dt = DT_BF16;
+  DeviceArena arena;
+  Workspace ws;
+  void* ws_mem = nullptr;
+  size_t ws_cap = 0;
+  int64_t nparams = 0;
+
+  float *te1_w = nullptr, *te1_b = nullptr, *te2_w = nullptr, *te2_b = nullptr;
+  float *tproj_w = nullptr, *tproj_b = nullptr;
+  int temb_total = 0;
+  ConvW conv_in, conv_out;
+  NormW norm_out;
+  ResnetW down_res[4][2], mid_res[2], up_res[4][3];
+  TransformerW down_attn[3][2], mid_attn, up_attn[4][3];  // up_attn[0] unused
+  ConvW down_conv[3], up_conv[3];
+  // sampler state
+  int plan_B = 0, plan_L = 0;
+  size_t plan_persist = 0, plan_scratch = 0;
+  float* cond = nullptr;   // [B,4,L,L] self-conditioning channel
+  float* eps = nullptr;
+  size_t loop_elems = 0;
+
+  ~ldmseg_unet() {
+    arena.release();
+    if (ws_mem) (void)hipFree(ws_mem);
+    if (cond) (void)hipFree(cond);
+    if (eps) (void)hipFree(eps);
+  }
+};
+
+namespace {
+
+int build_resnet(Builder& b, const std::string& p, int cin, int cout, int* temb_off, ResnetW* r) {
+  r->cin = cin; r->cout = cout;
+  TRY(b.norm(p + "norm1", cin, &r->norm1));
+  TRY(b.conv(p + "conv1", cout, cin, 3, cin, &r->conv1));
+  TRY(b.norm(p + "norm2", cout, &r->norm2));
+  TRY(b.conv(p + "conv2", cout, cout, 3, cout, &r->conv2));
+  r->has_shortcut = cin != cout;
+  if (r->has_shortcut) TRY(b.conv(p + "conv_shortcut", cout, cin, 1, cin, &r->shortcut));
+  r->temb_off = *temb_off;
+  *temb_off += cout;
+  return 0;
+}
+
+int build_transformer(Builder& b, const std::string& p, int C, TransformerW* t) {
+  t->C = C;
+  const int dt = b.dt;
+  TRY(b.norm(p + "norm", C, &t->norm));
+  TRY(b.conv(p + "proj_in", C, C, 1, C, &t->proj_in));
+  const std::string tb = p + "transformer_blocks.0.";
+  TRY(b.norm(tb + "norm1", C, &t->ln1));
+  // fused q|k|v projection, no bias
+  {
+    ConvW& q = t->qkv;
+    q.N = 3 * C; q.n_valid = 3 * C; q.cin_pad = C; q.taps = 1; q.cout = 3 * C;
+    TRY(b.arena->alloc(&q.w, (size_t)3 * C * C * esize(dt)));
+    const char* names[3] = {"attn1.to_q.weight", "attn1.to_k.weight", "attn1.to_v.weight"};
+    for (int i = 0; i < 3; ++i) {
+      const float* w;
+      TRY(b.wm->get(tb + names[i], (int64_t)C * C, &w));
+      TRY(launch_repack_conv(w, (char*)q.w + (size_t)i * C * C * esize(dt), C, C, 1, 1, C, C, dt, b.s));
+      b.nparams += (int64_t)C * C;
+    }
+    q.bias = nullptr;
+  }
+  TRY(b.conv(tb + "attn1.to_out.0", C, C, 1, C, &t->attn_out));
+  TRY(b.norm(tb + "norm3", C, &t->ln3));
+  // GEGLU projection [8C, C]: rows interleaved in 16-row (a | gate) pairs so one lane owns both halves
+  {
+    ConvW& f = t->ff1;
+    const int N = 8 * C;
+    f.N = N; f.n_valid = 4 * C; f.cin_pad = C; f.taps = 1; f.cout = 4 * C;
+    std::vector<int> map(N);
+    for (int r = 0; r < N; ++r) {
+      const int blk = r / 32, w = r % 32;
+      map[r] = (w < 16) ? blk * 16 + w : 4 * C + blk * 16 + (w - 16);
+    }
+    int* dmap;
+    TRY(b.upload_ints(map, &dmap));
+    const float *w, *bias;
+    TRY(b.wm->get(tb + "ff.net.0.proj.weight", (int64_t)N * C, &w));
+    TRY(b.wm->get(tb + "ff.net.0.proj.bias", N, &bias));
+    TRY(b.arena->alloc(&f.w, (size_t)N * C * esize(dt)));
+    TRY(launch_repack_rows(w, f.w, dmap, N, C, dt, b.s));
+    void* pb;
+    TRY(b.arena->alloc(&pb, N * sizeof(float)));
+    TRY(launch_repack_rows(bias, pb, dmap, N, 1, DT_F32, b.s));
+    f.bias = (float*)pb;
+    b.nparams += (int64_t)N * C + N;
+  }
+  TRY(b.conv(tb + "ff.net.2", C, 4 * C, 1, 4 * C, &t->ff2));
+  TRY(b.conv(p + "proj_out", C, C, 1, C, &t->proj_out));
+  return 0;
+}
+
+int unet_build(ldmseg_unet* u, const WeightMap& wm) {
+  hipStream_t s = nullptr;
+  Builder b{&u->arena, &wm, u->dt, s};
+  const int cp = bke(u->dt);
+  if (u->cfg.in_channels > cp) return fail(LDMSEG_E_ARG, "in_channels too large");
+  TRY(b.conv("conv_in", kBlockOut[0], u->cfg.in_channels, 3, cp, &u->conv_in));
+  TRY(b.f32_copy("time_embedding.linear_1.weight", (int64_t)kTimeDim * 320, &u->te1_w));
+  TRY(b.f32_copy("time_embedding.linear_1.bias", kTimeDim, &u->te1_b));
+  TRY(b.f32_copy("time_embedding.linear_2.weight", (int64_t)kTimeDim * kTimeDim, &u->te2_w));
+  TRY(b.f32_copy("time_embedding.linear_2.bias", kTimeDim, &u->te2_b));
+
+  int temb_off = 0;
+  std::vector<int> skip_ch{kBlockOut[0]};
+  int c = kBlockOut[0];
+  for (int i = 0; i < 4; ++i) {
+    const int co = kBlockOut[i];
+    for (int j = 0; j < 2; ++j) {
+      const std::string p = "down_blocks." + std::to_string(i);
+      TRY(build_resnet(b, p + ".resnets." + std::to_string(j) + ".", c, co, &temb_off, &u->down_res[i][j]));
+      c = co;
+      if (i < 3) TRY(build_transformer(b, p + ".attentions." + std::to_string(j) + ".", c, &u->down_attn[i][j]));
+      skip_ch.push_back(c);
+    }
+    if (i < 3) {
+      TRY(b.conv("down_blocks." + std::to_string(i) + ".downsamplers.0.conv", c, c, 3, c, &u->down_conv[i]));
+      skip_ch.push_back(c);
+    }
+  }
+  TRY(build_resnet(b, "mid_block.resnets.0.", c, c, &temb_off, &u->mid_res[0]));
+  TRY(build_transformer(b, "mid_block.attentions.0.", c, &u->mid_attn));
+  TRY(build_resnet(b, "mid_block.resnets.1.", c, c, &temb_off, &u->mid_res[1]));
+  for (int i = 0; i < 4; ++i) {
+    const int co = kBlockOut[3 - i];
+    for (int j = 0; j < 3; ++j) {
+      const std::string p = "up_blocks." + std::to_string(i);
+      const int sk = skip_ch.back();
+      skip_ch.pop_back();
+      TRY(build_resnet(b, p + ".resnets." + std::to_string(j) + ".", c + sk, co, &temb_off, &u->up_res[i][j]));
+      c = co;
+      if (i > 0) TRY(build_transformer(b, p + ".attentions." + std::to_string(j) + ".", c, &u->up_attn[i][j]));
+    }
+    if (i < 3) TRY(b.conv("up_blocks." + std::to_string(i) + ".upsamplers.0.conv", c, c, 3, c, &u->up_conv[i]));
+  }
+  TRY(b.norm("conv_norm_out", c, &u->norm_out));
+  TRY(b.conv("conv_out", 4, c, 3, c, &u->conv_out));
+
+  // all 22 time_emb_proj Linear(1280 -> cout) concatenated: one GEMV per forward
+  u->temb_total = temb_off;
+  {
+    void *pw, *pb;
+    TRY(u->arena.alloc(&pw, (size_t)temb_off * kTimeDim * sizeof(float)));
+    TRY(u->arena.alloc(&pb, (size_t)temb_off * sizeof(float)));
+    u->tproj_w = (float*)pw;
+    u->tproj_b = (float*)pb;
+    auto put = [&](const std::string& p, const ResnetW& r) -> int {
+      const float *w, *bias;
+      TRY(wm.get(p + "time_emb_proj.weight", (int64_t)r.cout * kTimeDim, &w));
+      TRY(wm.get(p + "time_emb_proj.bias", r.cout, &bias));
+      HIP_TRY(hipMemcpyAsync(u->tproj_w + (size_t)r.temb_off * kTimeDim, w, (size_t)r.cout * kTimeDim * sizeof(float),
+                             hipMemcpyDeviceToDevice, s));
+      HIP_TRY(hipMemcpyAsync(u->tproj_b + r.temb_off, bias, r.cout * sizeof(float), hipMemcpyDeviceToDevice, s));
+      b.nparams += (int64_t)r.cout * kTimeDim + r.cout;
+      return 0;
+    };
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 2; ++j)
+        TRY(put("down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j) + ".", u->down_res[i][j]));
+    TRY(put("mid_block.resnets.0.", u->mid_res[0]));
+    TRY(put("mid_block.resnets.1.", u->mid_res[1]));
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 3; ++j)
+        TRY(put("up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j) + ".", u->up_res[i][j]));
+  }
+  TRY(b.finish());
+  u->nparams = b.nparams;
+  return 0;
+}
+
+int run_resnet(Exec& ex, const ResnetW& r, const Act& x, const Act* skip, const float* temb, int temb_stride, Act* out) {
+  Workspace* ws = ex.ws;
+  // output first (persist), temporaries on the scratch stack
+  const size_t m = ws->mark();
+  Act n1, h1, n2, sc;
+  TRY(ex.groupnorm(r.norm1, x, skip, 1e-5f, 1, &n1));
+  TRY(ex.conv(r.conv1, n1, nullptr, &h1, 1, 0, false, temb + r.temb_off, temb_stride, nullptr));
+  TRY(ex.groupnorm(r.norm2, h1, nullptr, 1e-5f, 1, &n2));
+  const Act* resid = &x;
+  if (r.has_shortcut) {
+    TRY(ex.conv(r.shortcut, x, skip, &sc, 1, 0, false, nullptr, 0, nullptr));
+    resid = &sc;
+  } else if (skip) {
+    return fail(LDMSEG_E_SHAPE, "resnet without shortcut cannot take a concat input");
+  }
+  TRY(ex.conv(r.conv2, n2, nullptr, out, 1, 0, true, nullptr, 0, resid));
+  ws->reset(m);
+  return 0;
+}
+
+int run_transformer(Exec& ex, const TransformerW& t, const Act& x, Act* out) {
+  Workspace* ws = ex.ws;
+  const size_t m = ws->mark();
+  const int C = t.C, N = x.H * x.W, M = ex.B * N;
+  Act n, h, ln, qkv, att, ff;
+  TRY(ex.groupnorm(t.norm, x, nullptr, 1e-6f, 0, &n));
+  TRY(ex.conv(t.proj_in, n, nullptr, &h, 1, 0, false, nullptr, 0, nullptr));
+  TRY(ex.layernorm(t.ln1, h, 1e-5f, 0, &ln));
+  TRY(ex.conv(t.qkv, ln, nullptr, &qkv, 1, 0, false, nullptr, 0, nullptr));
+  att = ex.new_act(C, x.H, x.W, false);
+  {
+    const double d = C / 8.0;
+    ProfScope ps(1, ex.s, 4.0 * ex.B * 8 * (double)N * N * d, 4.0 * M * C * esize(ex.dt), ex.dry());
+    if (!ex.dry()) TRY(launch_attention(qkv.p, att.p, ex.B, N, C, 8, ex.dt, ex.s));
+  }
+  // h = to_out(att) + h  (in place on h)
+  {
+    IgemmParams p;
+    p.src0 = att.p; p.C0 = C; p.B = ex.B; p.Hi = p.Ho = x.H; p.Wi = p.Wo = x.W;
+    p.M = M; p.N = t.attn_out.N; p.n_valid = C; p.W = t.attn_out.w; p.bias = t.attn_out.bias;
+    p.resid = h.p; p.ldr = C; p.out = h.p; p.ldo = C;
+    TRY(ex.igemm(p));
+  }
+  TRY(ex.layernorm(t.ln3, h, 1e-5f, 0, &ln, false));
+  ff = ex.new_act(4 * C, x.H, x.W, false);
+  {
+    IgemmParams p;
+    p.src0 = ln.p; p.C0 = C; p.B = ex.B; p.Hi = p.Ho = x.H; p.Wi = p.Wo = x.W;
+    p.M = M; p.N = t.ff1.N; p.n_valid = 4 * C; p.W = t.ff1.w; p.bias = t.ff1.bias;
+    p.out = ff.p; p.ldo = 4 * C; p.epi = EPI_GEGLU;
+    TRY(ex.igemm(p));
+  }
+  {
+    IgemmParams p;
+    p.src0 = ff.p; p.C0 = 4 * C; p.B = ex.B; p.Hi = p.Ho = x.H; p.Wi = p.Wo = x.W;
+    p.M = M; p.N = t.ff2.N; p.n_valid = C; p.W = t.ff2.w; p.bias = t.ff2.bias;
+    p.resid = h.p; p.ldr = C; p.out = h.p; p.ldo = C;
+    TRY(ex.igemm(p));
+  }
+  TRY(ex.conv(t.proj_out, h, nullptr, out, 1, 0, true, nullptr, 0, &x));
+  ws->reset(m);
+  return 0;
+}
+
+// dry = true only measures the workspace
+int unet_forward_impl(ldmseg_unet* u, const float* a, int Ca, const float* b, int Cb, const float* c, int Cc,
+                      const int64_t* t_dev, int t_count, int64_t t_host, int B, int L, float* out, hipStream_t s,
+                      bool dry, size_t scratch_base) {
+  if (B < 1 || L < 8 || L % 8 != 0) return fail(LDMSEG_E_SHAPE, "L must be a positive multiple of 8, B >= 1");
+  if (Ca + Cb + Cc != u->cfg.in_channels) return fail(LDMSEG_E_SHAPE, "input channel count != in_channels");
+  if (t_dev && t_count != 1 && t_count != B) return fail(LDMSEG_E_ARG, "t_count must be 1 or B");
+  Workspace* ws = &u->ws;
+  ws->begin(dry, scratch_base);
+  Exec ex{ws, u->dt, B, s};
+  const int dt = u->dt;
+
+  // --- time embedding: sinusoid -> MLP -> every resnet's time_emb_proj(SiLU(emb)) ---
+  float* sinus = (float*)ws->persist((size_t)B * 320 * sizeof(float));
+  float* e1 = (float*)ws->persist((size_t)B * kTimeDim * sizeof(float));
+  float* emb = (float*)ws->persist((size_t)B * kTimeDim * sizeof(float));
+  float* temb = (float*)ws->persist((size_t)B * u->temb_total * sizeof(float));
+  {
+    ProfScope ps(4, s, 0, 0, dry);
+    if (!dry) {
+      TRY(launch_time_embed(t_dev, t_count, t_host, B, sinus, s));
+      TRY(launch_small_linear(sinus, u->te1_w, u->te1_b, e1, B, 320, kTimeDim, 0, 1, s));
+      TRY(launch_small_linear(e1, u->te2_w, u->te2_b, emb, B, kTimeDim, kTimeDim, 0, 0, s));
+      TRY(launch_small_linear(emb, u->tproj_w, u->tproj_b, temb, B, kTimeDim, u->temb_total, 1, 0, s));
+    }
+  }
+  const int tstride = u->temb_total;
+
+  // --- conv_in on the channel-concatenated fp32 NCHW input ---
+  Act xin = ex.new_act(bke(dt), L, L, true);
+  {
+    ProfScope ps(4, s, 0, 0, dry);
+    if (!dry) TRY(launch_pack_concat3(a, Ca, b, Cb, c, Cc, xin.p, B, L * L, bke(dt), dt, s));
+  }
+  Act h;
+  TRY(ex.conv(u->conv_in, xin, nullptr, &h, 1, 0, true, nullptr, 0, nullptr));
+  std::vector<Act> skips{h};
+
+  for (int i = 0; i < 4; ++i) {
+    for (int j = 0; j < 2; ++j) {
+      Act o;
+      TRY(run_resnet(ex, u->down_res[i][j], h, nullptr, temb, tstride, &o));
+      h = o;
+      if (i < 3) {
+        TRY(run_transformer(ex, u->down_attn[i][j], h, &o));
+        h = o;
+      }
+      skips.push_back(h);
+    }
+    if (i < 3) {
+      Act o;
+      TRY(ex.conv(u->down_conv[i], h, nullptr, &o, 2, 0, true, nullptr, 0, nullptr));
+      h = o;
+      skips.push_back(h);
+    }
+  }
+  {
+    Act o;
+    TRY(run_resnet(ex, u->mid_res[0], h, nullptr, temb, tstride, &o)); h = o;
+    TRY(run_transformer(ex, u->mid_attn, h, &o)); h = o;
+    TRY(run_resnet(ex, u->mid_res[1], h, nullptr, temb, tstride, &o)); h = o;
+  }
+  for (int i = 0; i < 4; ++i) {
+    for (int j = 0; j < 3; ++j) {
+      Act sk = skips.back();
+      skips.pop_back();
+      Act o;
+      TRY(run_resnet(ex, u->up_res[i][j], h, &sk, temb, tstride, &o));   // torch.cat([hidden, skip], 1)
+      h = o;
+      if (i > 0) {
+        TRY(run_transformer(ex, u->up_attn[i][j], h, &o));
+        h = o;
+      }
+    }
+    if (i < 3) {
+      Act o;
+      TRY(ex.conv(u->up_conv[i], h, nullptr, &o, 1, 1, true, nullptr, 0, nullptr));  // nearest x2 folded in
+      h = o;
+    }
+  }
+  // --- conv_norm_out -> SiLU -> conv_out, written straight to fp32 NCHW ---
+  {
+    const size_t m = ws->mark();
+    Act n;
+    TRY(ex.groupnorm(u->norm_out, h, nullptr, 1e-5f, 1, &n));
+    IgemmParams p;
+    p.src0 = n.p; p.C0 = n.C; p.B = B; p.Hi = p.Ho = L; p.Wi = p.Wo = L;
+    p.taps = 9; p.M = B * L * L; p.N = u->conv_out.N; p.n_valid = 4;
+    p.W = u->conv_out.w; p.bias = u->conv_out.bias; p.out = out; p.epi = EPI_NCHW_F32;
+    TRY(ex.igemm(p));
+    ws->reset(m);
+  }
+  return 0;
+}
+
+int ensure_ws(void** mem, size_t* cap, Workspace* ws, size_t need) {
+  if (need <= *cap) return 0;
+  if (*mem) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipFree(*mem));
+    *mem = nullptr;
+    *cap = 0;
+  }
+  if (hipMalloc(mem, need) != hipSuccess) return fail(LDMSEG_E_OOM, "workspace hipMalloc failed (" + std::to_string(need) + " bytes)");
+  *cap = need;
+  ws->base = (char*)*mem;
+  ws->cap = need;
+  return 0;
+}
+
+int unet_forward_checked(ldmseg_unet* u, const float* a, int Ca, const float* b, int Cb, const float* c, int Cc,
+                         const int64_t* t_dev, int t_count, int64_t t_host, int B, int L, float* out, hipStream_t s) {
+  // measure (cached per shape), (re)allocate, run
+  if (u->plan_B != B || u->plan_L != L) {
+    TRY(unet_forward_impl(u, a, Ca, b, Cb, c, Cc, t_dev, t_count, t_host, B, L, out, s, true, 0));
+    u->plan_persist = rup(u->ws.persist_peak, 4096);
+    u->plan_scratch = rup(u->ws.scratch_peak, 4096);
+    u->plan_B = B;
+    u->plan_L = L;
+  }
+  TRY(ensure_ws(&u->ws_mem, &u->ws_cap, &u->ws, u->plan_persist + u->plan_scratch));
+  return unet_forward_impl(u, a, Ca, b, Cb, c, Cc, t_dev, t_count, t_host, B, L, out, s, false, u->plan_persist);
+}
+
+int check_arch(int device) {
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(LDMSEG_E_ARCH, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+  return 0;
+}
+
+int make_weight_map(int n, const char* const* names, const void* const* ptrs, const int64_t* numels, WeightMap* wm) {
+  if (!names || !ptrs || !numels) return fail(LDMSEG_E_ARG, "null weight arrays");
+  for (int i = 0; i < n; ++i) wm->m[names[i]] = {(const float*)ptrs[i], numels[i]};
+  return 0;
+}
+
+}  // namespace
+
+// =================================================================== seg-VAE
+struct ldmseg_vae {
+  ldmseg_vae_cfg cfg{};
+  int dt = DT_BF16;
+  DeviceArena arena;
+  Workspace ws;
+  void* ws_mem = nullptr;
+  size_t ws_cap = 0;
+  int64_t nparams = 0;
+  // encoder
+  ConvW enc[10];          // encoder.{0,2,3,5,6,8,9,11,15} in order (9 used)
+  NormW enc_gn;
+  int enc_ch[5]{};        // storage channel counts
+  // decoder
+  ConvW dec_in, dec_out;
+  ConvW convt[4];
+  NormW ln[4], dec_gn;
+  ~ldmseg_vae() {
+    arena.release();
+    if (ws_mem) (void)hipFree(ws_mem);
+  }
+};
+
+namespace {
+
+inline int cstore(int c, int dt) { return (int)rup(c, bke(dt)); }
+
+int vae_build(ldmseg_vae* v, const WeightMap& wm) {
+  hipStream_t s = nullptr;
+  const ldmseg_vae_cfg& c = v->cfg;
+  const int dt = v->dt;
+  Builder b{&v->arena, &wm, dt, s};
+  if (c.in_channels > bke(dt) || c.latent_channels > bke(dt)) return fail(LDMSEG_E_ARG, "too many boundary channels");
+  if (c.int_channels % 64 || c.upscale_channels % 64 || c.num_upscalers < 1 || c.num_upscalers > 4)
+    return fail(LDMSEG_E_ARG, "unsupported seg-VAE configuration");
+  // ---- encoder (vae.py:174-244) ----
+  const int* boc = c.block_out_channels;
+  int k = 0;
+  TRY(b.conv("encoder.0", boc[0], c.in_channels, 3, bke(dt), &v->enc[k++], true, cstore(boc[0], dt)));
+  int idx = 2;
+  for (int i = 0; i < 3; ++i) {
+    TRY(b.conv("encoder." + std::to_string(idx), boc[i], boc[i], 3, cstore(boc[i], dt), &v->enc[k++], true, cstore(boc[i], dt)));
+    TRY(b.conv("encoder." + std::to_string(idx + 1), boc[i + 1], boc[i], 3, cstore(boc[i], dt), &v->enc[k++], true,
+               cstore(boc[i + 1], dt)));
+    idx += 3;
+  }
+  TRY(b.conv("encoder." + std::to_string(idx), c.int_channels, boc[3], 3, cstore(boc[3], dt), &v->enc[k++]));
+  TRY(b.norm("encoder." + std::to_string(idx + 2), c.int_channels, &v->enc_gn));
+  TRY(b.conv("encoder." + std::to_string(idx + 4), c.latent_channels * c.num_latents, c.int_channels, 3, c.int_channels,
+             &v->enc[k++]));
+  // ---- decoder (vae.py:123-172) ----
+  TRY(b.conv("decoder.0", c.int_channels, c.latent_channels, 3, bke(dt), &v->dec_in));
+  idx = 2;
+  int cin = c.int_channels;
+  for (int i = 0; i < c.num_upscalers; ++i) {
+    ConvW& t = v->convt[i];
+    const int Co = c.upscale_channels;
+    const float *w, *bias;
+    TRY(wm.get("decoder." + std::to_string(idx) + ".weight", (int64_t)cin * Co * 4, &w));
+    TRY(wm.get("decoder." + std::to_string(idx) + ".bias", Co, &bias));
+    t.N = 4 * Co; t.n_valid = 4 * Co; t.cin_pad = cin; t.taps = 1; t.cout = Co;
+    TRY(v->arena.alloc(&t.w, (size_t)4 * Co * cin * esize(dt)));
+    TRY(launch_repack_convt2(w, t.w, cin, Co, dt, s));
+    void* pb;
+    TRY(v->arena.alloc(&pb, (size_t)4 * Co * sizeof(float)));
+    for (int q = 0; q < 4; ++q)
+      HIP_TRY(hipMemcpyAsync((float*)pb + q * Co, bias, Co * sizeof(float), hipMemcpyDeviceToDevice, s));
+    t.bias = (float*)pb;
+    b.nparams += (int64_t)cin * Co * 4 + Co;
+    TRY(b.norm("decoder." + std::to_string(idx + 1), Co, &v->ln[i]));
+    cin = Co;
+    idx += 3;
+  }
+  TRY(b.norm("decoder." + std::to_string(idx), cin, &v->dec_gn));
+  TRY(b.conv("decoder." + std::to_string(idx + 2), c.out_channels, cin, 3, cin, &v->dec_out));
+  TRY(b.finish());
+  v->nparams = b.nparams;
+  return 0;
+}
+
+int vae_decode_impl(ldmseg_vae* v, const float* z, float z_scale, int B, int L, int interpolate, float* logits,
+                    hipStream_t s, bool dry, size_t scratch_base) {
+  Workspace* ws = &v->ws;
+  ws->begin(dry, scratch_base);
+  Exec ex{ws, v->dt, B, s};
+  const int dt = v->dt;
+  const ldmseg_vae_cfg& c = v->cfg;
+  Act zin = ex.new_act(bke(dt), L, L, true);
+  {
+    ProfScope ps(4, s, 0, 0, dry);
+    if (!dry) TRY(launch_pack_nchw(z, zin.p, B, c.latent_channels, L * L, bke(dt), z_scale, 0.f, dt, s));
+  }
+  Act h;
+  TRY(ex.conv(v->dec_in, zin, nullptr, &h, 1, 0, true, nullptr, 0, nullptr));
+  for (int i = 0; i < c.num_upscalers; ++i) {
+    const ConvW& t = v->convt[i];
+    Act o = ex.new_act(t.cout, 2 * h.H, 2 * h.W, true);
+    IgemmParams p;
+    p.src0 = h.p; p.C0 = h.C; p.B = B; p.Hi = p.Ho = h.H; p.Wi = p.Wo = h.W;
+    p.M = B * h.H * h.W; p.N = t.N; p.n_valid = t.N; p.W = t.w; p.bias = t.bias;
+    p.out = o.p; p.ldo = t.cout; p.epi = EPI_CONVT2; p.cout = t.cout;
+    TRY(ex.igemm(p));
+    Act n;
+    TRY(ex.layernorm(v->ln[i], o, 1e-6f, 1, &n, true));   // LayerNorm2d + SiLU, in place
+    h = n;
+  }
+  Act g;
+  TRY(ex.groupnorm(v->dec_gn, h, nullptr, 1e-5f, 1, &g));
+  const int H4 = h.H, W4 = h.W;
+  IgemmParams p;
+  p.src0 = g.p; p.C0 = g.C; p.B = B; p.Hi = p.Ho = H4; p.Wi = p.Wo = W4;
+  p.taps = 9; p.M = B * H4 * W4; p.N = v->dec_out.N; p.n_valid = c.out_channels;
+  p.W = v->dec_out.w; p.bias = v->dec_out.bias;
+  if (!interpolate) {
+    p.out = logits; p.epi = EPI_NCHW_F32;
+    TRY(ex.igemm(p));
+  } else {
+    Act lo = ex.new_act(c.out_channels, H4, W4, false);
+    p.out = lo.p; p.ldo = c.out_channels; p.epi = EPI_STORE;
+    TRY(ex.igemm(p));
+    ProfScope ps(4, s, 0, (double)B * H4 * W4 * c.out_channels * (esize(dt) + 16.0), dry);
+    if (!dry) TRY(launch_bilinear2x_nchw(lo.p, logits, B, H4, W4, c.out_channels, dt, s));
+  }
+  return 0;
+}
+
+int vae_encode_impl(ldmseg_vae* v, const float* x, float mul, float add, int B, int H, float* moments, hipStream_t s,
+                    bool dry, size_t scratch_base) {
+  Workspace* ws = &v->ws;
+  ws->begin(dry, scratch_base);
+  Exec ex{ws, v->dt, B, s};
+  const int dt = v->dt;
+  const ldmseg_vae_cfg& c = v->cfg;
+  Act xin = ex.new_act(bke(dt), H, H, true);
+  {
+    ProfScope ps(4, s, 0, 0, dry);
+    if (!dry) TRY(launch_pack_nchw(x, xin.p, B, c.in_channels, H * H, bke(dt), mul, add, dt, s));
+  }
+  Act h, o;
+  int k = 0;
+  TRY(ex.conv(v->enc[k++], xin, nullptr, &h, 1, 0, true, nullptr, 0, nullptr, 1));  // conv + SiLU
+  for (int i = 0; i < 3; ++i) {
+    TRY(ex.conv(v->enc[k++], h, nullptr, &o, 1, 0, true, nullptr, 0, nullptr, 0)); h = o;
+    TRY(ex.conv(v->enc[k++], h, nullptr, &o, 2, 0, true, nullptr, 0, nullptr, 1)); h = o;
+  }
+  TRY(ex.conv(v->enc[k++], h, nullptr, &o, 1, 0, true, nullptr, 0, nullptr, 0)); h = o;
+  Act g;
+  TRY(ex.groupnorm(v->enc_gn, h, nullptr, 1e-6f, 1, &g));
+  const ConvW& last = v->enc[k];
+  IgemmParams p;
+  p.src0 = g.p; p.C0 = g.C; p.B = B; p.Hi = p.Ho = h.H; p.Wi = p.Wo = h.W;
+  p.taps = 9; p.M = B * h.H * h.W; p.N = last.N; p.n_valid = c.latent_channels * c.num_latents;
+  p.W = last.w; p.bias = last.bias; p.out = moments; p.epi = EPI_NCHW_F32;
+  TRY(ex.igemm(p));
+  return 0;
+}
+
+}  // namespace
+
+// =================================================================== C ABI
+extern "C" {
+
+const char* ldmseg_last_error(void) { return g_err.c_str(); }
+const char* ldmseg_version(void) { return "ldmseg_hip 0.1 (gfx950)"; }
+
+int ldmseg_unet_create(const ldmseg_unet_cfg* cfg, int n_weights, const char* const* names,
+                       const void* const* dev_ptrs, const int64_t* numels, ldmseg_unet** out) {
+  g_err.clear();
+  if (!cfg || !out) return fail(LDMSEG_E_ARG, "null argument");
+  if (cfg->cross_attention) return fail(LDMSEG_E_ARG, "cross-attention (encoder_hidden_states) is not supported: the reference default removes it (base.yaml:71)");
+  if (cfg->compute_dtype != LDMSEG_F32 && cfg->compute_dtype != LDMSEG_BF16) return fail(LDMSEG_E_ARG, "bad compute_dtype");
+  if (cfg->in_channels != 4 && cfg->in_channels != 8 && cfg->in_channels != 12) return fail(LDMSEG_E_ARG, "in_channels must be 4, 8 or 12");
+  HIP_TRY(hipSetDevice(cfg->device));
+  TRY(check_arch(cfg->device));
+  WeightMap wm;
+  TRY(make_weight_map(n_weights, names, dev_ptrs, numels, &wm));
+  ldmseg_unet* u = new ldmseg_unet();
+  u->cfg = *cfg;
+  u->dt = cfg->compute_dtype == LDMSEG_BF16 ? DT_BF16 : DT_F32;
+  const int r = unet_build(u, wm);
+  if (r != 0) { delete u; return r; }
+  *out = u;
+  return 0;
+}
+
+void ldmseg_unet_destroy(ldmseg_unet* h) { delete h; }
+
+int64_t ldmseg_unet_num_params(const ldmseg_unet* h) { return h ? h->nparams : 0; }
+
+size_t ldmseg_unet_workspace_bytes(const ldmseg_unet* h, int B, int L) {
+  if (!h) return 0;
+  ldmseg_unet* u = const_cast<ldmseg_unet*>(h);
+  const int ci = u->cfg.in_channels;
+  if (unet_forward_impl(u, nullptr, ci, nullptr, 0, nullptr, 0, nullptr, 1, 0, B, L, nullptr, nullptr, true, 0) != 0) return 0;
+  return rup(u->ws.persist_peak, 4096) + rup(u->ws.scratch_peak, 4096);
+}
+
+int ldmseg_unet_forward(ldmseg_unet* h, const float* x, const int64_t* t_dev, int t_count, int64_t t_host, int B, int L,
+                        float* out, void* stream) {
+  g_err.clear();
+  if (!h || !x || !out) return fail(LDMSEG_E_ARG, "null argument");
+  return unet_forward_checked(h, x, h->cfg.in_channels, nullptr, 0, nullptr, 0, t_dev, t_count, t_host, B, L, out,
+                              (hipStream_t)stream);
+}
+
+int ldmseg_unet_forward_parts(ldmseg_unet* h, const float* latents, const float* rgb_latents, const float* cond,
+                              const int64_t* t_dev, int t_count, int64_t t_host, int B, int L, float* out, void* stream) {
+  g_err.clear();
+  if (!h || !latents || !rgb_latents || !out) return fail(LDMSEG_E_ARG, "null argument");
+  return unet_forward_checked(h, latents, 4, rgb_latents, 4, cond, cond ? 4 : 0, t_dev, t_count, t_host, B, L, out,
+                              (hipStream_t)stream);
+}
+
+int ldmseg_vae_create(const ldmseg_vae_cfg* cfg, int n_weights, const char* const* names, const void* const* dev_ptrs,
+                      const int64_t* numels, ldmseg_vae** out) {
+  g_err.clear();
+  if (!cfg || !out) return fail(LDMSEG_E_ARG, "null argument");
+  if (cfg->compute_dtype != LDMSEG_F32 && cfg->compute_dtype != LDMSEG_BF16) return fail(LDMSEG_E_ARG, "bad compute_dtype");
+  if (cfg->num_latents != 2 || cfg->norm_num_groups != 32) return fail(LDMSEG_E_ARG, "only the gaussian parametrization with 32 groups is supported");
+  HIP_TRY(hipSetDevice(cfg->device));
+  TRY(check_arch(cfg->device));
+  WeightMap wm;
+  TRY(make_weight_map(n_weights, names, dev_ptrs, numels, &wm));
+  ldmseg_vae* v = new ldmseg_vae();
+  v->cfg = *cfg;
+  v->dt = cfg->compute_dtype == LDMSEG_BF16 ? DT_BF16 : DT_F32;
+  const int r = vae_build(v, wm);
+  if (r != 0) { delete v; return r; }
+  *out = v;
+  return 0;
+}
+void ldmseg_vae_destroy(ldmseg_vae* h) { delete h; }
+int64_t ldmseg_vae_num_params(const ldmseg_vae* h) { return h ? h->nparams : 0; }
+
+int ldmseg_vae_decode(ldmseg_vae* h, const float* z, float z_scale, int B, int L, int interpolate, float* logits,
+                      void* stream) {
+  g_err.clear();
+  if (!h || !z || !logits) return fail(LDMSEG_E_ARG, "null argument");
+  if (B < 1 || L < 1) return fail(LDMSEG_E_SHAPE, "bad B/L");
+  TRY(vae_decode_impl(h, z, z_scale, B, L, interpolate, logits, (hipStream_t)stream, true, 0));
+  const size_t persist = rup(h->ws.persist_peak, 4096), scratch = rup(h->ws.scratch_peak, 4096);
+  TRY(ensure_ws(&h->ws_mem, &h->ws_cap, &h->ws, persist + scratch));
+  return vae_decode_impl(h, z, z_scale, B, L, interpolate, logits, (hipStream_t)stream, false, persist);
+}
+
+int ldmseg_vae_encode(ldmseg_vae* h, const float* x, float in_mul, float in_add, int B, int H, float* moments,
+                      void* stream) {
+  g_err.clear();
+  if (!h || !x || !moments) return fail(LDMSEG_E_ARG, "null argument");
+  if (B < 1 || H < 8 || H % 8) return fail(LDMSEG_E_SHAPE, "H must be a multiple of 8");
+  TRY(vae_encode_impl(h, x, in_mul, in_add, B, H, moments, (hipStream_t)stream, true, 0));
+  const size_t persist = rup(h->ws.persist_peak, 4096), scratch = rup(h->ws.scratch_peak, 4096);
+  TRY(ensure_ws(&h->ws_mem, &h->ws_cap, &h->ws, persist + scratch));
+  return vae_encode_impl(h, x, in_mul, in_add, B, H, moments, (hipStream_t)stream, false, persist);
+}
+
+int ldmseg_vae_posterior(const float* moments, const float* noise, float out_scale, int B, int l, float* out,
+                         void* stream) {
+  g_err.clear();
+  if (!moments || !out) return fail(LDMSEG_E_ARG, "null argument");
+  TRY(launch_posterior_sample(moments, noise, out, B, l * l, (hipStream_t)stream));
+  if (out_scale != 1.0f) TRY(launch_axpby(out, out_scale, 0.f, out, (size_t)B * 4 * l * l, (hipStream_t)stream));
+  return 0;
+}
+
+int ldmseg_ddim_step(const float* model_output, const float* sample, float sqrt_alpha_t, float sqrt_beta_t,
+                     float sqrt_alpha_prev, float sqrt_beta_prev, int prediction_type, int clip_sample,
+                     float clip_sample_range, int use_clipped_model_output, float* prev_sample,
+                     float* pred_original_sample, size_t n, void* stream) {
+  g_err.clear();
+  if (!model_output || !sample) return fail(LDMSEG_E_ARG, "null argument");
+  if (prediction_type < 0 || prediction_type > 2) return fail(LDMSEG_E_ARG, "unknown prediction_type");
+  DdimCoef c{sqrt_alpha_t, sqrt_beta_t, sqrt_alpha_prev, sqrt_beta_prev, prediction_type, clip_sample, clip_sample_range,
+             use_clipped_model_output};
+  TRY(launch_ddim_step(model_output, sample, prev_sample, pred_original_sample, n, c, (hipStream_t)stream));
+  return 0;
+}
+
+int ldmseg_add_noise(const float* original, const float* noise, const int64_t* timesteps_dev,
+                     const float* alphas_cumprod_dev, float scale, float* out, int B, size_t per_sample, void* stream) {
+  g_err.clear();
+  TRY(launch_add_noise(original, noise, timesteps_dev, alphas_cumprod_dev, scale, out, B, per_sample, 0, (hipStream_t)stream));
+  return 0;
+}
+int ldmseg_remove_noise(const float* noisy, const float* noise, const int64_t* timesteps_dev,
+                        const float* alphas_cumprod_dev, float scale, float* out, int B, size_t per_sample, void* stream) {
+  g_err.clear();
+  TRY(launch_add_noise(noisy, noise, timesteps_dev, alphas_cumprod_dev, scale, out, B, per_sample, 1, (hipStream_t)stream));
+  return 0;
+}
+
+int ldmseg_sample_loop(ldmseg_unet* h, const ldmseg_sample_cfg* cfg, float* latents, const float* rgb_latents, int B, int L,
+                       float* all_latents, void* stream) {
+  g_err.clear();
+  if (!h || !cfg || !latents || !rgb_latents || !cfg->timesteps || !cfg->coef) return fail(LDMSEG_E_ARG, "null argument");
+  hipStream_t s = (hipStream_t)stream;
+  const size_t n = (size_t)B * 4 * L * L;
+  const bool selfc = cfg->self_condition != 0;
+  if ((h->cfg.in_channels == 12) != selfc) return fail(LDMSEG_E_ARG, "self_condition needs the 12-channel conv_in (and vice versa)");
+  if (h->loop_elems < n) {
+    HIP_TRY(hipDeviceSynchronize());
+    if (h->cond) (void)hipFree(h->cond);
+    if (h->eps) (void)hipFree(h->eps);
+    h->cond = h->eps = nullptr;
+    HIP_TRY(hipMalloc((void**)&h->cond, n * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&h->eps, n * sizeof(float)));
+    h->loop_elems = n;
+  }
+  const bool inpaint = cfg->known_dev != nullptr;
+  if (inpaint && (!cfg->z0_dev || !cfg->noise_dev || !cfg->paste_coef)) return fail(LDMSEG_E_ARG, "inpainting needs z0, noise and paste_coef");
+  if (selfc) HIP_TRY(hipMemsetAsync(h->cond, 0, n * sizeof(float), s));   // condition = zeros_like(rgb_latents)
+  for (int i = 0; i < cfg->n_steps; ++i) {
+    TRY(unet_forward_checked(h, latents, 4, rgb_latents, 4, selfc ? h->cond : nullptr, selfc ? 4 : 0, nullptr, 1,
+                             cfg->timesteps[i], B, L, h->eps, s));
+    const float* c = cfg->coef + 4 * i;
+    DdimCoef dc{c[0], c[1], c[2], c[3], cfg->prediction_type, cfg->clip_sample, cfg->clip_sample_range, 0};
+    const bool last = (i == cfg->n_steps - 1);
+    // condition <- pred_original_sample; latents <- prev_sample (last step: pred_original_sample)
+    if (!last) {
+      TRY(launch_ddim_step(h->eps, latents, latents, selfc ? h->cond : nullptr, n, dc, s));
+    } else {
+      TRY(launch_ddim_step(h->eps, latents, nullptr, latents, n, dc, s));
+    }
+    if (inpaint)
+      TRY(launch_inpaint_paste(latents, cfg->z0_dev, cfg->noise_dev, cfg->known_dev, cfg->paste_coef[2 * i],
+                               cfg->paste_coef[2 * i + 1], B, 4, L * L, s));
+    if (all_latents)
+      HIP_TRY(hipMemcpyAsync(all_latents + (size_t)i * n, latents, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+  }
+  return 0;
+}
+
+int ldmseg_profile_enable(int enable) {
+  g_prof.on = enable != 0;
+  return 0;
+}
+int ldmseg_profile_reset(void) {
+  for (auto& f : g_prof.fam) {
+    for (auto& e : f.ev) { g_prof.pool.push_back(e.first); g_prof.pool.push_back(e.second); }
+    f.ev.clear();
+    f.launches = 0;
+    f.flops = f.bytes = 0;
+  }
+  return 0;
+}
+int ldmseg_profile_read(int family, int64_t* launches, double* total_ms, double* flops, double* bytes) {
+  g_err.clear();
+  if (family < 0 || family > 4) return fail(LDMSEG_E_ARG, "family must be 0..4");
+  ProfFamily& f = g_prof.fam[family];
+  double ms = 0;
+  for (auto& e : f.ev) {
+    HIP_TRY(hipEventSynchronize(e.second));
+    float t = 0;
+    HIP_TRY(hipEventElapsedTime(&t, e.first, e.second));
+    ms += t;
+  }
+  if (launches) *launches = f.launches;
+  if (total_ms) *total_ms = ms;
+  if (flops) *flops = f.flops;
+  if (bytes) *bytes = f.bytes;
+  return 0;
+}
+
+}  // extern "C"

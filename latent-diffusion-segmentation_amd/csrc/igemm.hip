@@ -1,0 +1,368 @@
+// Implicit-GEMM convolution / GEMM for gfx950 (CDNA4), the kernel ~84 % of the
+// UNet's FLOPs run through: conv3x3 (stride 1/2, optional folded nearest-x2
+// upsample, optional channel-concat of two sources), conv1x1 and Linear, in
+// NHWC, bf16 (v_mfma_f32_16x16x32_bf16) or exact f32 (v_mfma_f32_16x16x4_f32).
+//
+//   out[m][n] = sum_k X[m][k] * W[n][k]      m = (b, oy, ox), k = (tap, channel)
+//
+// Design (see DESIGN.md "igemm"):
+//  * X rows are gathered on the fly: a K tile is 128 B of one tap (64 bf16 /
+//    32 f32 channels), so every 16-B chunk a lane fetches is contiguous in HBM
+//    and 8 lanes cover one full 128-B line.  Padding / out-of-image taps are
+//    predicated to zero; the upsample is an index shift; torch.cat([h,skip])
+//    is a pointer switch at a K-tile boundary (all channel counts are
+//    multiples of 64).
+//  * W is pre-packed [N][K] so both operands are K-contiguous: the same
+//    ds_read_b128 pattern feeds either MFMA operand.  Operands are swapped
+//    (MFMA A = W, B = X) so a lane ends up holding 4 consecutive n of one m:
+//    8-/16-byte stores along the NHWC channel axis and in-lane GEGLU.
+//  * LDS tiles are [rows][128 B] with the 16-B chunk index XOR (row & 7):
+//    conflict-free for ds_read_b128 over the 16-lane groups of gfx950.
+//  * double-buffered LDS, register-staged global loads issued before the MFMA
+//    block of the current tile, one barrier per K tile, 2 workgroups per CU.
+//  * workgroup id -> (m tile, n tile) is remapped so that each XCD (own L2)
+//    owns a contiguous range of tiles.
+#include "common.h"
+#include "kernels.h"
+
+namespace ldmseg {
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kRowBytes = 128;
+
+struct RowInfo {
+  int pix_base;  // b * Hi * Wi
+  int iy0, ix0;  // top-left input coordinate (logical, before upsample shift)
+};
+
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(kThreads) void igemm_kernel(const IgemmParams p) {
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+  constexpr int BKE = kRowBytes / (int)sizeof(T);  // K elements per tile
+  constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+  constexpr int MF = WTM / 16, NF = WTN / 16;
+  constexpr int AI = BM * 8 / kThreads;  // 16-B chunks of X per thread per tile
+  constexpr int WI = BN * 8 / kThreads;
+  static_assert(BM * 8 % kThreads == 0 && BN * 8 % kThreads == 0, "tile/loader mismatch");
+  constexpr int kStageBytes = (BM + BN) * kRowBytes;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+  // ---- XCD-aware tile assignment (bijective for any grid size) ----
+  const int NT = p.N / BN;
+  int wg;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int mt = wg / NT, nt = wg % NT;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  const int Ctot = p.C0 + p.C1;
+  const int K = p.taps * Ctot;
+  const int nk_total = K / BKE;
+  int kt_begin = 0, kt_end = nk_total;
+  if (p.splits > 1) {
+    const int z = blockIdx.y;
+    kt_begin = (int)((long)nk_total * z / p.splits);
+    kt_end = (int)((long)nk_total * (z + 1) / p.splits);
+  }
+
+  const int Hlog = p.up ? 2 * p.Hi : p.Hi;
+  const int Wlog = p.up ? 2 * p.Wi : p.Wi;
+  const int pad = (p.taps == 9) ? 1 : 0;
+  const int HWo = p.Ho * p.Wo;
+
+  // ---- per-thread gather rows ----
+  const int ld_j = tid & 7;                 // logical 16-B chunk within the 128-B K tile row
+  const int ld_r = tid >> 3;                // row within a 32-row pass
+  const int ld_sw = (ld_j ^ (ld_r & 7)) * 16;
+  RowInfo ri[AI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    const int m = m0 + i * 32 + ld_r;
+    if (m < p.M) {
+      const int b = m / HWo, rem = m - b * HWo;
+      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      ri[i].pix_base = b * p.Hi * p.Wi;
+      ri[i].iy0 = oy * p.stride - pad;
+      ri[i].ix0 = ox * p.stride - pad;
+    } else {
+      ri[i].pix_base = 0;
+      ri[i].iy0 = -(1 << 28);
+      ri[i].ix0 = 0;
+    }
+  }
+  const unsigned char* wbase = (const unsigned char*)p.W + ((size_t)(n0 + ld_r) * K) * sizeof(T) + ld_j * 16;
+  const size_t wrow_stride32 = (size_t)32 * K * sizeof(T);
+
+  uint4 xa[AI], wa[WI];
+
+  // tap / channel cursor of the tile being fetched
+  int f_tap = 0, f_cc = 0;
+  {
+    const int kt = kt_begin;
+    const int tiles_per_tap = Ctot / BKE;
+    f_tap = kt / tiles_per_tap;
+    f_cc = (kt - f_tap * tiles_per_tap) * BKE;
+  }
+
+  auto fetch = [&](int kt) {
+    const int ky = (p.taps == 9) ? f_tap / 3 : 0;
+    const int kx = (p.taps == 9) ? f_tap - ky * 3 : 0;
+    const unsigned char* sbase;
+    int cs, coff;
+    if (f_cc < p.C0) { sbase = (const unsigned char*)p.src0; cs = p.C0; coff = f_cc; }
+    else { sbase = (const unsigned char*)p.src1; cs = p.C1; coff = f_cc - p.C0; }
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int uy = ri[i].iy0 + ky, ux = ri[i].ix0 + kx;
+      const bool inb = (uy >= 0) & (uy < Hlog) & (ux >= 0) & (ux < Wlog);
+      const int iy = p.up ? (uy >> 1) : uy, ix = p.up ? (ux >> 1) : ux;
+      const size_t off = ((size_t)(ri[i].pix_base + iy * p.Wi + ix) * cs + coff) * sizeof(T) + ld_j * 16;
+      xa[i] = inb ? *(const uint4*)(sbase + off) : make_uint4(0, 0, 0, 0);
+    }
+    const unsigned char* wp = wbase + (size_t)kt * kRowBytes;
+#pragma unroll
+    for (int i = 0; i < WI; ++i) wa[i] = *(const uint4*)(wp + i * wrow_stride32);
+    f_cc += BKE;
+    if (f_cc == Ctot) { f_cc = 0; ++f_tap; }
+  };
+  auto stash = [&](int stage) {
+    unsigned char* xs = smem + stage * kStageBytes;
+    unsigned char* ws = xs + BM * kRowBytes;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) *(uint4*)(xs + (i * 32 + ld_r) * kRowBytes + ld_sw) = xa[i];
+#pragma unroll
+    for (int i = 0; i < WI; ++i) *(uint4*)(ws + (i * 32 + ld_r) * kRowBytes + ld_sw) = wa[i];
+  };
+
+  f32x4 acc[NF][MF];
+#pragma unroll
+  for (int a = 0; a < NF; ++a)
+#pragma unroll
+    for (int b = 0; b < MF; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment read offsets: row = frag*16 + (lane&15); chunk = kg*4 + (lane>>4), XOR (row&7)
+  const int fr_row = (lane & 15) * kRowBytes;
+  const int fr_c0 = (((lane >> 4)) ^ (lane & 7)) * 16;
+  const int fr_c1 = (((lane >> 4) + 4) ^ (lane & 7)) * 16;
+
+  if (kt_begin < kt_end) {
+    fetch(kt_begin);
+    stash(0);
+  }
+  __syncthreads();
+
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int cur = (kt - kt_begin) & 1;
+    const bool more = (kt + 1 < kt_end);
+    if (more) fetch(kt + 1);
+    const unsigned char* xs = smem + cur * kStageBytes + (wm * WTM) * kRowBytes + fr_row;
+    const unsigned char* ws = smem + cur * kStageBytes + (BM + wn * WTN) * kRowBytes + fr_row;
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg) {
+      const int co = kg ? fr_c1 : fr_c0;
+      uint4 wf[NF], xf[MF];
+#pragma unroll
+      for (int a = 0; a < NF; ++a) wf[a] = *(const uint4*)(ws + a * 16 * kRowBytes + co);
+#pragma unroll
+      for (int b = 0; b < MF; ++b) xf[b] = *(const uint4*)(xs + b * 16 * kRowBytes + co);
+#pragma unroll
+      for (int a = 0; a < NF; ++a)
+#pragma unroll
+        for (int b = 0; b < MF; ++b) mma_kgroup<T>(wf[a], xf[b], acc[a][b]);
+    }
+    if (more) stash(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds n = nb + 4*(lane>>4) + r (r=0..3) of m = mb + (lane&15) ----
+  const int lg = lane >> 4;
+#pragma unroll
+  for (int b = 0; b < MF; ++b) {
+    const int m = m0 + wm * WTM + b * 16 + (lane & 15);
+    if (m >= p.M) continue;
+    if (p.splits > 1) {
+      float* dst = p.partial + ((size_t)blockIdx.y * p.M + m) * p.N;
+#pragma unroll
+      for (int a = 0; a < NF; ++a) {
+        const int n = n0 + wn * WTN + a * 16 + lg * 4;
+        *(f32x4*)(dst + n) = acc[a][b];
+      }
+      continue;
+    }
+    const int bimg = m / HWo;
+    if (p.epi == EPI_GEGLU) {
+      if constexpr (NF % 2 == 0) {
+#pragma unroll
+        for (int a = 0; a < NF; a += 2) {
+          const int n = n0 + wn * WTN + a * 16 + lg * 4;
+          const int oc = ((n0 + wn * WTN + a * 16) >> 1) + lg * 4;
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float av = acc[a][b][r] + p.bias[n + r];
+            const float gv = acc[a + 1][b][r] + p.bias[n + 16 + r];
+            v[r] = av * gelu_erf_f(gv);
+          }
+          T* o = (T*)p.out + (size_t)m * p.ldo + oc;
+          if constexpr (sizeof(T) == 2) {
+            *(uint2*)o = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+          } else {
+            *(f32x4*)o = f32x4{v[0], v[1], v[2], v[3]};
+          }
+        }
+      }
+      continue;
+    }
+#pragma unroll
+    for (int a = 0; a < NF; ++a) {
+      const int n = n0 + wn * WTN + a * 16 + lg * 4;
+      if (n >= p.n_valid) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[a][b][r];
+      if (p.bias) {
+        const f32x4 bv = *(const f32x4*)(p.bias + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += bv[r];
+      }
+      if (p.rowbias) {
+        const f32x4 bv = *(const f32x4*)(p.rowbias + (size_t)bimg * p.rb_stride + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += bv[r];
+      }
+      if (p.epi == EPI_STORE) {
+        if (p.resid) {
+          const T* rp = (const T*)p.resid + (size_t)m * p.ldr + n;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += to_f32<T>(rp[r]);
+        }
+        if (p.silu) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
+        }
+        T* o = (T*)p.out + (size_t)m * p.ldo + n;
+        if constexpr (sizeof(T) == 2) {
+          *(uint2*)o = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+        } else {
+          *(f32x4*)o = f32x4{v[0], v[1], v[2], v[3]};
+        }
+      } else if (p.epi == EPI_NCHW_F32) {
+        const int pix = m - bimg * HWo;
+        float* o = (float*)p.out + ((size_t)bimg * p.n_valid + n) * HWo + pix;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (n + r < p.n_valid) o[(size_t)r * HWo] = p.silu ? silu_f(v[r]) : v[r];
+      } else {  // EPI_CONVT2
+        const int tap = n / p.cout, co = n - tap * p.cout;
+        const int dy = tap >> 1, dx = tap & 1;
+        const int rem = m - bimg * HWo;
+        const int y = rem / p.Wo, x = rem - y * p.Wo;
+        const size_t orow = ((size_t)bimg * 2 * p.Ho + 2 * y + dy) * (2 * p.Wo) + 2 * x + dx;
+        T* o = (T*)p.out + orow * p.ldo + co;
+        if constexpr (sizeof(T) == 2) {
+          *(uint2*)o = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+        } else {
+          *(f32x4*)o = f32x4{v[0], v[1], v[2], v[3]};
+        }
+      }
+    }
+  }
+}
+
+// split-K finish: out = sum_z partial[z] + bias (+rowbias)(+resid), optional SiLU  (EPI_STORE only)
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const IgemmParams p) {
+  const int nq = p.n_valid >> 2;
+  const size_t total = (size_t)p.M * nq;
+  const int HWo = p.Ho * p.Wo;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int m = (int)(i / nq), n = (int)(i - (size_t)m * nq) * 4;
+    f32x4 v = *(const f32x4*)(p.partial + (size_t)m * p.N + n);
+    for (int z = 1; z < p.splits; ++z) v += *(const f32x4*)(p.partial + ((size_t)z * p.M + m) * p.N + n);
+    if (p.bias) v += *(const f32x4*)(p.bias + n);
+    if (p.rowbias) v += *(const f32x4*)(p.rowbias + (size_t)(m / HWo) * p.rb_stride + n);
+    if (p.resid) {
+      const T* rp = (const T*)p.resid + (size_t)m * p.ldr + n;
+      for (int r = 0; r < 4; ++r) v[r] += to_f32<T>(rp[r]);
+    }
+    if (p.silu) for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
+    T* o = (T*)p.out + (size_t)m * p.ldo + n;
+    if constexpr (sizeof(T) == 2) {
+      *(uint2*)o = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+    } else {
+      *(f32x4*)o = v;
+    }
+  }
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+int run(const IgemmParams& p, hipStream_t s) {
+  const int mt = (p.M + BM - 1) / BM, nt = p.N / BN;
+  const size_t lds = 2 * (size_t)(BM + BN) * kRowBytes;
+  auto kern = igemm_kernel<T, BM, BN, WM, WN>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  dim3 grid(mt * nt, p.splits > 1 ? p.splits : 1);
+  hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, s, p);
+  if (p.splits > 1) {
+    const size_t total = (size_t)p.M * (p.n_valid >> 2);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_finish_kernel<T>, dim3(blocks), dim3(256), 0, s, p);
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+template <typename T>
+int dispatch(const IgemmParams& p, hipStream_t s) {
+  const int bn = (p.epi == EPI_GEGLU) ? 128 : (p.N % 160 == 0 ? 160 : (p.N % 128 == 0 ? 128 : (p.N % 64 == 0 ? 64 : 32)));
+  // under-filled grids: halve the M tile so more CUs get work
+  const bool small = (long)((p.M + 127) / 128) * (p.N / bn) < 200;
+  switch (bn) {
+    case 160: return small ? run<T, 64, 160, 2, 2>(p, s) : run<T, 128, 160, 2, 2>(p, s);
+    case 128: return small ? run<T, 64, 128, 2, 2>(p, s) : run<T, 128, 128, 2, 2>(p, s);
+    case 64: return run<T, 128, 64, 4, 1>(p, s);
+    default: return run<T, 128, 32, 4, 1>(p, s);
+  }
+}
+
+}  // namespace
+
+int igemm_pick_bn(int n_real, int epi) {
+  if (epi == EPI_GEGLU) return 128;
+  if (n_real % 160 == 0) return 160;
+  if (n_real >= 128) return 128;
+  if (n_real > 32) return 64;
+  return 32;
+}
+
+size_t igemm_partial_bytes(const IgemmParams& p) {
+  return p.splits > 1 ? (size_t)p.splits * p.M * p.N * sizeof(float) : 0;
+}
+
+int launch_igemm(const IgemmParams& p, int dtype, hipStream_t s) {
+  const int bke = dtype == DT_BF16 ? 64 : 32;
+  if (p.M <= 0 || p.N <= 0 || p.N % 32 != 0) return -2;
+  if (p.C0 % bke != 0 || p.C1 % bke != 0 || (p.C0 + p.C1) == 0) return -2;
+  if (p.taps != 1 && p.taps != 9) return -2;
+  if (p.n_valid % 4 != 0 && p.epi != EPI_NCHW_F32) return -2;
+  if (p.epi == EPI_GEGLU && p.N % 128 != 0) return -2;
+  if (p.splits > 1 && (p.epi != EPI_STORE || p.partial == nullptr)) return -2;
+  return dtype == DT_BF16 ? dispatch<bf16_t>(p, s) : dispatch<float>(p, s);
+}
+
+}  // namespace ldmseg

@@ -1,0 +1,111 @@
+// Host-side launch API of the gfx950 kernels (internal; the public boundary is
+// include/ldmseg_hip.h).  All tensors are NHWC ("[B, H*W, C]") in the compute
+// dtype (bf16 or f32) unless a name says otherwise.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ldmseg {
+
+enum DType : int { DT_F32 = 0, DT_BF16 = 1 };
+
+enum Epilogue : int {
+  EPI_STORE = 0,   // out[m][n] = acc + bias (+rowbias) (+resid), optional SiLU
+  EPI_GEGLU = 1,   // packed (a,g) 16-column interleave -> out[m][n/2] = a*gelu(g)
+  EPI_NCHW_F32 = 2,  // out is float NCHW [B][n_valid][Ho*Wo]  (conv_out, VAE heads)
+  EPI_CONVT2 = 3,  // ConvTranspose2d k2s2: n = tap*Cout + co scattered to (2y+dy,2x+dx)
+};
+
+struct IgemmParams {
+  const void* src0 = nullptr;  // [B, Hi*Wi, C0]
+  const void* src1 = nullptr;  // [B, Hi*Wi, C1]  channel-concat partner (torch.cat([h, skip],1))
+  int C0 = 0, C1 = 0;
+  int B = 0, Hi = 0, Wi = 0, Ho = 0, Wo = 0;
+  int taps = 1;     // 1 (1x1 conv / Linear) or 9 (3x3, pad 1)
+  int stride = 1;   // 1 | 2
+  int up = 0;       // nearest x2 upsample folded into the gather (Upsample2D)
+  int M = 0;        // B*Ho*Wo
+  int N = 0;        // packed rows of W (multiple of the N tile)
+  int n_valid = 0;  // real output channels (store mask)
+  const void* W = nullptr;       // [N][taps*(C0+C1)] compute dtype, K = (tap, channel)
+  const float* bias = nullptr;   // [N] (packed order) or null
+  const float* rowbias = nullptr;  // [B][rb_stride] per-image bias (time embedding) or null
+  int rb_stride = 0;
+  const void* resid = nullptr;   // [M][ldr] residual, compute dtype, may alias out
+  int ldr = 0;
+  void* out = nullptr;
+  int ldo = 0;
+  int epi = EPI_STORE;
+  int silu = 0;
+  int cout = 0;     // EPI_CONVT2: real Cout per tap
+  // split-K: when splits>1 partial sums go to `partial` [splits][M][N] f32 and
+  // igemm_splitk_finish applies the epilogue.
+  int splits = 1;
+  float* partial = nullptr;
+};
+
+// returns 0 or a negative error (bad shape)
+int launch_igemm(const IgemmParams& p, int dtype, hipStream_t s);
+size_t igemm_partial_bytes(const IgemmParams& p);
+// tile the launcher would pick (for weight padding): N tile size for a given N.
+int igemm_pick_bn(int n_real, int epi);
+
+struct GNParams {
+  const void* src0 = nullptr; const void* src1 = nullptr;
+  int C0 = 0, C1 = 0, B = 0, HW = 0, groups = 32;
+  const float* gamma = nullptr; const float* beta = nullptr;
+  float eps = 1e-5f; int silu = 0;
+  void* out = nullptr;         // [B, HW, C0+C1]
+  float* partial = nullptr;    // workspace [B][nchunk][groups][2]
+  int nchunk = 0;
+};
+int gn_nchunk(int B, int HW);
+int launch_groupnorm(const GNParams& p, int dtype, hipStream_t s);
+
+// LayerNorm over the last dim of [M][C] (+ optional SiLU) - also LayerNorm2d in NHWC
+int launch_layernorm(const void* x, void* y, const float* gamma, const float* beta, int M, int C,
+                     float eps, int silu, int dtype, hipStream_t s);
+
+// self-attention on fused qkv [B, N, 3C] (q | k | v, channel = head*d + i) -> out [B, N, C]
+int launch_attention(const void* qkv, void* out, int B, int N, int C, int heads, int dtype, hipStream_t s);
+
+// NCHW f32 [B,C,HW] -> NHWC compute dtype [B,HW,Cpad] (zero padded channels), optional affine a*x+b
+int launch_pack_nchw(const float* x, void* y, int B, int C, int HW, int Cpad, float mul, float add,
+                     int dtype, hipStream_t s);
+// three NCHW f32 sources concatenated on channels (torch.cat([latents, rgb, cond],1)); null = skip
+int launch_pack_concat3(const float* a, int Ca, const float* b, int Cb, const float* c, int Cc,
+                        void* y, int B, int HW, int Cpad, int dtype, hipStream_t s);
+
+// timestep embedding + time MLP + all time_emb_proj: see misc.hip
+int launch_time_embed(const int64_t* t_dev, int t_count, int64_t t_host, int B, float* sinus /*[B,320]*/,
+                      hipStream_t s);
+// y[B][N] = act_in(x[B][K]) @ W[N][K]^T + bias ; f32 small-M GEMV (M<=64)
+int launch_small_linear(const float* x, const float* W, const float* bias, float* y, int B, int K, int N,
+                        int silu_in, int silu_out, hipStream_t s);
+
+// bilinear x2 (align_corners=False) NHWC compute dtype [B,H,W,C] -> NCHW f32 [B,C,2H,2W]
+int launch_bilinear2x_nchw(const void* x, float* y, int B, int H, int W, int C, int dtype, hipStream_t s);
+
+// weight repack (f32 torch layout -> compute dtype [N][K])
+// conv OIHW [Co][Ci][kh][kw] -> [Npad][kh*kw][Cipad] ; rows >= Co and channels >= Ci are zero
+int launch_repack_conv(const float* w, void* out, int Co, int Ci, int KH, int KW, int Npad, int Cipad,
+                       int dtype, hipStream_t s);
+// generic row gather: out[r][:] = (src_row[r] >= 0) ? w[src_row[r]][0:K] : 0  (Linear, GEGLU interleave, qkv concat)
+int launch_repack_rows(const float* w, void* out, const int* src_row_dev, int Npad, int K, int dtype, hipStream_t s);
+// ConvTranspose2d [Ci][Co][2][2] -> [4*Co][Ci]  (n = (dy*2+dx)*Co + co)
+int launch_repack_convt2(const float* w, void* out, int Ci, int Co, int dtype, hipStream_t s);
+
+// DDIM step (ddim_scheduler.py:218-269), elementwise, bit-exact op order
+struct DdimCoef { float sqrt_a_t, sqrt_b_t, sqrt_a_prev, sqrt_b_prev; int pred_type; int clip; float clip_range; int use_clipped; };
+int launch_ddim_step(const float* eps, const float* x, float* prev, float* x0, size_t n, DdimCoef c, hipStream_t s);
+// out = m ? (sa*z0 + sb*noise) : cur   (inpainting paste; m is u8 [B,1,L,L] broadcast on channels)
+int launch_inpaint_paste(float* cur, const float* z0, const float* noise, const uint8_t* known, float sa, float sb,
+                         int B, int C, int HW, hipStream_t s);
+// add_noise / remove_noise with per-sample timesteps (ddim_scheduler.py:155-216)
+int launch_add_noise(const float* x0, const float* noise, const int64_t* t_dev, const float* ac_dev, float scale,
+                     float* out, int B, size_t per, int remove, hipStream_t s);
+int launch_axpby(const float* x, float a, float b, float* y, size_t n, hipStream_t s);  // y = a*x + b
+// mean + exp(0.5*clamp(logvar))*noise on NCHW moments [B,8,HW] -> [B,4,HW]
+int launch_posterior_sample(const float* moments, const float* noise, float* out, int B, int HW, hipStream_t s);
+
+}  // namespace ldmseg

@@ -1,0 +1,241 @@
+// GroupNorm(32) [+SiLU] and LayerNorm [+SiLU] over NHWC activations (HBM-bound).
+//
+// GroupNorm runs as two launches over [B, HW, C]:
+//   1. gn_partial: each workgroup owns a pixel chunk of one image, streams whole
+//      rows with 16-B loads (every lane a fixed channel vector, so the group of
+//      each element is a per-thread constant), and writes per-(chunk, group)
+//      {sum, sumsq} partials in a fixed order (deterministic, no atomics).
+//   2. gn_apply: reduces the partials of its image (tiny), then normalises,
+//      applies gamma/beta (+SiLU) and writes the tensor the next conv gathers.
+//      Two sources are read as one channel-concatenated tensor, which is how
+//      torch.cat([hidden, skip], 1) disappears from the up path.
+// LayerNorm: one wavefront per row, values kept in registers, two-pass mean /
+// centred variance with wave shuffles (DPP) - same arithmetic as torch.
+#include "common.h"
+#include "kernels.h"
+
+namespace ldmseg {
+namespace {
+
+constexpr int kMaxIter = 4;   // ceil(nvec / 256) supported (C*sizeof(T)/16 <= 1024)
+
+template <typename T>
+__device__ __forceinline__ uint4 load_cat(const GNParams& p, int b, int pix, int v) {
+  constexpr int PC = Chunk<T>::N;
+  const int c = v * PC;
+  if (c < p.C0) return *(const uint4*)((const T*)p.src0 + ((size_t)b * p.HW + pix) * p.C0 + c);
+  return *(const uint4*)((const T*)p.src1 + ((size_t)b * p.HW + pix) * p.C1 + (c - p.C0));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_partial_kernel(const GNParams p) {
+  constexpr int PC = Chunk<T>::N;
+  const int C = p.C0 + p.C1;
+  const int cpg = C / p.groups;
+  const int nvec = C / PC;
+  const int VX = nvec < 256 ? nvec : 256;
+  const int TY = 256 / VX;
+  const int tid = threadIdx.x;
+  const int tx = tid % VX, ty = tid / VX;
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int per = (p.HW + p.nchunk - 1) / p.nchunk;
+  const int p0 = chunk * per;
+  const int p1 = min(p.HW, p0 + per);
+
+  __shared__ float red[kMaxIter][256][4];
+
+  const int niter = (nvec + VX - 1) / VX;
+  for (int it = 0; it < niter; ++it) {
+    const int v = tx + it * VX;
+    float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+    if (ty < TY && v < nvec) {
+      const int c0 = v * PC;
+      const int g0 = c0 / cpg;
+      const int split = min(PC, (g0 + 1) * cpg - c0);  // elements [0,split) -> g0, rest -> g0+1
+      for (int pix = p0 + ty; pix < p1; pix += TY) {
+        const uint4 raw = load_cat<T>(p, b, pix, v);
+        float f[PC];
+        Chunk<T>::unpack(raw, f);
+#pragma unroll
+        for (int e = 0; e < PC; ++e) {
+          if (e < split) { s0 += f[e]; q0 += f[e] * f[e]; }
+          else { s1 += f[e]; q1 += f[e] * f[e]; }
+        }
+      }
+    }
+    red[it][tid][0] = s0; red[it][tid][1] = q0; red[it][tid][2] = s1; red[it][tid][3] = q1;
+  }
+  __syncthreads();
+  // fixed-order reduction: thread j -> (group j>>1, stat j&1)
+  if (tid < 2 * p.groups) {
+    const int g = tid >> 1, st = tid & 1;
+    const int c_lo = g * cpg, c_hi = c_lo + cpg - 1;
+    // vectors overlapping channels [c_lo, c_hi]: low part feeds g when g0==g, high part when g0+1==g
+    const int v_first = max(0, c_lo / PC - 1);
+    const int v_last = min(nvec - 1, c_hi / PC);
+    double acc = 0.0;
+    for (int v = v_first; v <= v_last; ++v) {
+      const int g0 = (v * PC) / cpg;
+      const int it = v / VX, x = v - it * VX;
+      if (g0 == g) {
+        for (int y = 0; y < TY; ++y) acc += (double)red[it][y * VX + x][st];
+      } else if (g0 + 1 == g) {
+        for (int y = 0; y < TY; ++y) acc += (double)red[it][y * VX + x][2 + st];
+      }
+    }
+    p.partial[(((size_t)b * p.nchunk + chunk) * p.groups + g) * 2 + st] = (float)acc;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const GNParams p) {
+  constexpr int PC = Chunk<T>::N;
+  const int C = p.C0 + p.C1;
+  const int cpg = C / p.groups;
+  const int nvec = C / PC;
+  const int b = blockIdx.y;
+  __shared__ float s_mean[64], s_rstd[64];
+  if ((int)threadIdx.x < p.groups) {
+    const int g = threadIdx.x;
+    double s = 0.0, q = 0.0;
+    for (int ch = 0; ch < p.nchunk; ++ch) {
+      const float* pp = p.partial + (((size_t)b * p.nchunk + ch) * p.groups + g) * 2;
+      s += (double)pp[0];
+      q += (double)pp[1];
+    }
+    const double n = (double)p.HW * cpg;
+    const double mean = s / n;
+    double var = q / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    s_mean[g] = (float)mean;
+    s_rstd[g] = (float)(1.0 / sqrt(var + (double)p.eps));
+  }
+  __syncthreads();
+  const size_t total = (size_t)p.HW * nvec;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int pix = (int)(i / nvec), v = (int)(i - (size_t)pix * nvec);
+    const uint4 raw = load_cat<T>(p, b, pix, v);
+    float f[PC];
+    Chunk<T>::unpack(raw, f);
+    const int c0 = v * PC;
+#pragma unroll
+    for (int e = 0; e < PC; ++e) {
+      const int c = c0 + e;
+      const int g = c / cpg;
+      float y = (f[e] - s_mean[g]) * s_rstd[g] * p.gamma[c] + p.beta[c];
+      if (p.silu) y = silu_f(y);
+      f[e] = y;
+    }
+    *(uint4*)((T*)p.out + ((size_t)b * p.HW + pix) * C + c0) = Chunk<T>::pack(f);
+  }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// one wave per row; C*sizeof(T)/16 <= 64*VPL chunks
+template <typename T, int VPL>
+__global__ __launch_bounds__(256) void layernorm_kernel(const T* x, T* y, const float* gamma, const float* beta,
+                                                        int M, int C, float eps, int silu) {
+  constexpr int PC = Chunk<T>::N;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nvec = C / PC;
+  float f[VPL][PC];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < VPL; ++k) {
+    const int v = lane + k * 64;
+    if (v < nvec) {
+      const uint4 raw = *(const uint4*)(x + (size_t)row * C + v * PC);
+      Chunk<T>::unpack(raw, f[k]);
+#pragma unroll
+      for (int e = 0; e < PC; ++e) s += f[k][e];
+    }
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < VPL; ++k) {
+    const int v = lane + k * 64;
+    if (v < nvec) {
+#pragma unroll
+      for (int e = 0; e < PC; ++e) { const float d = f[k][e] - mean; q += d * d; }
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+  for (int k = 0; k < VPL; ++k) {
+    const int v = lane + k * 64;
+    if (v < nvec) {
+      const int c0 = v * PC;
+#pragma unroll
+      for (int e = 0; e < PC; ++e) {
+        float o = (f[k][e] - mean) * rstd * gamma[c0 + e] + beta[c0 + e];
+        if (silu) o = silu_f(o);
+        f[k][e] = o;
+      }
+      *(uint4*)(y + (size_t)row * C + c0) = Chunk<T>::pack(f[k]);
+    }
+  }
+}
+
+template <typename T>
+int run_gn(const GNParams& p, hipStream_t s) {
+  constexpr int PC = Chunk<T>::N;
+  const int C = p.C0 + p.C1;
+  if (C % p.groups != 0 || C % PC != 0 || p.C0 % PC != 0 || p.groups > 64) return -2;
+  if (C / p.groups < PC) return -2;               // a 16-B vector may span at most two groups
+  if (C / PC > 256 * kMaxIter) return -2;
+  hipLaunchKernelGGL(gn_partial_kernel<T>, dim3(p.nchunk, p.B), dim3(256), 0, s, p);
+  const size_t total = (size_t)p.HW * (C / PC);
+  int blocks = (int)((total + 255) / 256);
+  const int cap = max(1, 2048 / p.B);
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(blocks, p.B), dim3(256), 0, s, p);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+template <typename T>
+int run_ln(const void* x, void* y, const float* g, const float* b, int M, int C, float eps, int silu, hipStream_t s) {
+  constexpr int PC = Chunk<T>::N;
+  if (C % PC != 0) return -2;
+  const int nvec = C / PC;
+  const int vpl = (nvec + 63) / 64;
+  dim3 grid((M + 3) / 4), block(256);
+  switch (vpl) {
+    case 1: hipLaunchKernelGGL((layernorm_kernel<T, 1>), grid, block, 0, s, (const T*)x, (T*)y, g, b, M, C, eps, silu); break;
+    case 2: hipLaunchKernelGGL((layernorm_kernel<T, 2>), grid, block, 0, s, (const T*)x, (T*)y, g, b, M, C, eps, silu); break;
+    case 3: hipLaunchKernelGGL((layernorm_kernel<T, 3>), grid, block, 0, s, (const T*)x, (T*)y, g, b, M, C, eps, silu); break;
+    case 4: case 5: hipLaunchKernelGGL((layernorm_kernel<T, 5>), grid, block, 0, s, (const T*)x, (T*)y, g, b, M, C, eps, silu); break;
+    default: return -2;
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+}  // namespace
+
+int gn_nchunk(int B, int HW) {
+  // ~512-1024 workgroups in total, at least 8 pixels per chunk
+  int n = 768 / (B > 0 ? B : 1);
+  if (n < 1) n = 1;
+  if (n > 128) n = 128;
+  while (n > 1 && HW / n < 8) n >>= 1;
+  return n;
+}
+
+int launch_groupnorm(const GNParams& p, int dtype, hipStream_t s) {
+  return dtype == DT_BF16 ? run_gn<bf16_t>(p, s) : run_gn<float>(p, s);
+}
+
+int launch_layernorm(const void* x, void* y, const float* gamma, const float* beta, int M, int C, float eps,
+                     int silu, int dtype, hipStream_t s) {
+  return dtype == DT_BF16 ? run_ln<bf16_t>(x, y, gamma, beta, M, C, eps, silu, s)
+                          : run_ln<float>(x, y, gamma, beta, M, C, eps, silu, s);
+}
+
+}  // namespace ldmseg

@@ -1,0 +1,159 @@
+"""Segmentation VAE with the reference's call surface, executed by the gfx950 library.
+
+Stands behind /root/reference/ldmseg/models/vae.py::GeneralVAESeg for the
+default (gaussian, num_mid_blocks=0) configuration of base.yaml:14-33:
+
+    logits = vae_semseg.decode(z)                           # trainers_ldm_cond.py:422
+    z = vae_semseg.encode(x).latent_dist.mode() / .sample() # trainers_ldm_cond.py:371-375
+"""
+import ctypes as C
+from typing import Optional, Tuple, Union
+
+import torch
+
+from .. import _lib
+from ..utils import EncoderOutput, VAEOutput
+from ..weights import vae_schema
+
+
+class DiagonalGaussianDistribution(object):
+    """vae.py:370-424 on device moments [B, 8, l, l] (mean | logvar)."""
+
+    def __init__(self, parameters: torch.Tensor, clamp_output: bool = False, act_fn: str = 'none'):
+        if clamp_output or act_fn != 'none':
+            raise NotImplementedError("only clamp_output=False / act_fn='none' (base.yaml:25-26)")
+        self.parameters = parameters
+        self.clamp_output = clamp_output
+        self.act_fn = act_fn
+
+    def _posterior(self, noise):
+        p = self.parameters
+        B, _, l, _ = p.shape
+        out = torch.empty((B, 4, l, l), device=p.device, dtype=torch.float32)
+        with torch.cuda.device(p.device):
+            _lib.check(_lib.lib().ldmseg_vae_posterior(_lib.ptr(p), _lib.ptr(noise), 1.0, B, l, _lib.ptr(out),
+                                                       _lib.stream_ptr(p.device)), "ldmseg_vae_posterior")
+        return out
+
+    @property
+    def mean(self):
+        return self.parameters[:, :4]
+
+    @property
+    def logvar(self):
+        return torch.clamp(self.parameters[:, 4:], -30.0, 20.0)
+
+    def mode(self):
+        return self._posterior(None)
+
+    def sample(self, generator: Optional[torch.Generator] = None) -> torch.Tensor:
+        p = self.parameters
+        shape = (p.shape[0], 4, p.shape[2], p.shape[3])
+        noise = torch.randn(shape, generator=generator, device=p.device, dtype=p.dtype)
+        return self._posterior(noise)
+
+
+class GeneralVAESeg(object):
+    def __init__(self, state_dict, in_channels: int = 7, int_channels: int = 256, out_channels: int = 128,
+                 block_out_channels: Tuple[int] = (32, 64, 128, 256), latent_channels: int = 4,
+                 norm_num_groups: int = 32, scaling_factor: float = 0.18215, num_mid_blocks: int = 0,
+                 num_latents: int = 2, num_upscalers: int = 2, upscale_channels: int = 256,
+                 parametrization: str = 'gaussian', act_fn: str = 'none', clamp_output: bool = False,
+                 device: Union[str, torch.device] = "cuda:0", compute_dtype="bf16", **unused):
+        if parametrization != 'gaussian' or num_mid_blocks != 0 or len(block_out_channels) != 4:
+            raise NotImplementedError("only the default gaussian seg-VAE without mid blocks is built")
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("GeneralVAESeg needs an MI355X device (no CPU fallback)")
+        self.scaling_factor = scaling_factor
+        self.downsample_factor = 2 ** (len(block_out_channels) - 1)
+        self.interpolation_factor = self.downsample_factor // (2 ** num_upscalers)
+        if self.interpolation_factor not in (1, 2):
+            raise NotImplementedError("interpolation factor must be 1 or 2")
+        self.parametrization = parametrization
+        self.num_latents = num_latents
+        self.act_fn = act_fn
+        self.clamp_output = clamp_output
+        self.out_channels = out_channels
+        self.dtype = torch.float32
+        schema = vae_schema(in_channels, int_channels, out_channels, block_out_channels, latent_channels,
+                            num_latents, num_upscalers, upscale_channels)
+        state_dict = {k.replace('module.', ''): v for k, v in state_dict.items()}   # vae.py:119
+        missing = [k for k in schema if k not in state_dict]
+        if missing:
+            raise KeyError(f"state dict lacks seg-VAE tensors, e.g. {missing[:3]}")
+        cd = {"bf16": _lib.BF16, torch.bfloat16: _lib.BF16, "fp32": _lib.F32, torch.float32: _lib.F32,
+              "float32": _lib.F32, "bfloat16": _lib.BF16}[compute_dtype]
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        cfg = _lib.VAECfg(in_channels, int_channels, out_channels, latent_channels, num_latents, num_upscalers,
+                          upscale_channels, norm_num_groups, (C.c_int32 * 4)(*block_out_channels), cd, idx)
+        n, names, ptrs, numels, keep = _lib.weight_arrays(state_dict, self.device)
+        handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            torch.cuda.synchronize(self.device)
+            _lib.check(_lib.lib().ldmseg_vae_create(C.byref(cfg), n, names, ptrs, numels, C.byref(handle)),
+                       "ldmseg_vae_create")
+        del keep
+        self._h = handle
+        self._in_channels = in_channels
+        self._upscale = 2 ** num_upscalers
+
+    @property
+    def num_parameters(self) -> int:
+        return int(_lib.lib().ldmseg_vae_num_params(self._h))
+
+    def eval(self):
+        return self
+
+    def to(self, *_a, **_k):
+        return self
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                _lib.lib().ldmseg_vae_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    def encode_moments(self, semseg: torch.Tensor, in_mul: float = 1.0, in_add: float = 0.0) -> torch.Tensor:
+        x = _lib.require_cuda_f32(semseg, "semseg")
+        B, Cin, H, W = x.shape
+        if Cin != self._in_channels or H != W:
+            raise ValueError(f"expected [B,{self._in_channels},H,H], got {tuple(x.shape)}")
+        l = H // self.downsample_factor
+        mom = torch.empty((B, 8, l, l), device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().ldmseg_vae_encode(self._h, _lib.ptr(x), in_mul, in_add, B, H, _lib.ptr(mom),
+                                                    _lib.stream_ptr(x.device)), "ldmseg_vae_encode")
+        return mom
+
+    def encode(self, semseg: torch.Tensor) -> EncoderOutput:
+        return EncoderOutput(latent_dist=DiagonalGaussianDistribution(self.encode_moments(semseg)))
+
+    def decode(self, z: torch.Tensor, interpolate: bool = True, z_scale: float = 1.0) -> torch.Tensor:
+        z = _lib.require_cuda_f32(z, "z")
+        B, _, L, _ = z.shape
+        up = self._upscale * L * (self.interpolation_factor if interpolate else 1)
+        interp = 1 if (interpolate and self.interpolation_factor == 2) else 0
+        out = torch.empty((B, self.out_channels, up, up), device=z.device, dtype=torch.float32)
+        with torch.cuda.device(z.device):
+            _lib.check(_lib.lib().ldmseg_vae_decode(self._h, _lib.ptr(z), float(z_scale), B, L, interp, _lib.ptr(out),
+                                                    _lib.stream_ptr(z.device)), "ldmseg_vae_decode")
+        return out
+
+    def forward(self, sample, sample_posterior: bool = True, return_dict: bool = True,
+                generator: Optional[torch.Generator] = None, rgb_sample=None, valid_mask=None):
+        if rgb_sample is not None:
+            raise NotImplementedError("fuse_rgb is off in base.yaml:30")
+        posterior = self.encode(sample).latent_dist
+        z = posterior.sample(generator=generator) if sample_posterior else posterior.mode()
+        if valid_mask is not None:
+            z = z * valid_mask[:, None]
+        dec = self.decode(z, interpolate=False)
+        if not return_dict:
+            return (dec,)
+        return VAEOutput(sample=dec, posterior=posterior)
+
+    __call__ = forward

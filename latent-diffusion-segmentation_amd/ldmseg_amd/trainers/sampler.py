@@ -1,0 +1,228 @@
+"""Sampling entry points with the reference's call surface.
+
+Stands behind the hot-path methods of
+/root/reference/ldmseg/trainers/trainers_ldm_cond.py::TrainerDiffusion:
+
+    sample(prompts, num_inference_steps, guidance_scale, seed, rgb_latents, ...)   # :1045-1170
+    decode_latents(latents, return_logits=True)                                   # :397-442
+    encode_inputs(images, encode_func=vae_semseg.encode, scaling_factor=...)      # :335-394 (seg side)
+
+plus two things the reference does elsewhere or not at all:
+  * ``sample_sharded`` - the data-parallel eval decomposition the reference gets from
+    DistributedSampler (:245): independent images are split over ranks, each rank runs
+    the whole loop locally and ONE RCCL all-gather of the final latents replaces the
+    detectron2 ``comm.gather`` of PNGs (evaluations/panoptic_evaluation_agnostic.py:129-131);
+  * ``sample_inpaint`` - the build-defined mask-inpainting sampler.
+
+Training, logging, datasets and PQ evaluation are out of scope.
+"""
+import ctypes as C
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+
+class TrainerDiffusion(object):
+    def __init__(self, vae_semseg, unet, noise_scheduler, self_condition: Optional[bool] = None,
+                 device=None, latent_size: int = 64):
+        self.vae_semseg = vae_semseg
+        self.unet_model = unet
+        self.noise_scheduler = noise_scheduler
+        self.self_condition = (unet.in_channels == 12) if self_condition is None else bool(self_condition)
+        self.device = torch.device(device) if device is not None else unet.device
+        self.args = {'gpu': self.device}
+        self.latent_size = latent_size
+        self.unet_dtype = torch.float32
+        self.image_descriptor_model = None
+        self.textencoder = None
+        self.tokenizer = None
+
+    # ------------------------------------------------------------------ noise
+    @staticmethod
+    def draw_noise(batch_size: int, latent_size: int, seed: Optional[int]) -> torch.Tensor:
+        """CPU generator draw, identical for every batch of a given size (:1088-1091)."""
+        g = torch.Generator().manual_seed(seed) if seed is not None else None
+        return torch.randn((batch_size, 4, latent_size, latent_size), generator=g)
+
+    # ------------------------------------------------------------------ sample
+    @torch.no_grad()
+    def sample(self, prompts: List[str], num_inference_steps: int = 50, guidance_scale: float = 7.5,
+               seed: Optional[int] = None, rgb_latents: Optional[torch.Tensor] = None,
+               return_all_latents: bool = False, disable_progress_bar: bool = False,
+               rgb_images: Optional[torch.Tensor] = None, scheduler=None, repeat_noise: Optional[bool] = None,
+               python_loop: bool = False, latents: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """DDIM sampling loop.  ``python_loop=True`` walks ``scheduler.timesteps`` in Python calling
+        ``unet(...)`` and ``scheduler.step(...)`` exactly like the reference; the default hands the
+        whole loop to ldmseg_sample_loop (same kernels, no per-step Python)."""
+        if rgb_latents is None:
+            raise ValueError("rgb_latents is required (the reference dereferences it at :1126)")
+        if scheduler is None:
+            scheduler = self.noise_scheduler
+            scheduler.set_timesteps_inference(num_inference_steps)
+        repeat_noise = bool(repeat_noise)
+        batch_size = len(prompts)
+        rgb = _lib.require_cuda_f32(rgb_latents, "rgb_latents")
+        L = rgb.shape[-1]
+        if latents is None:
+            latents = self.draw_noise(batch_size, L, seed)
+        latents = latents.to(device=rgb.device, dtype=torch.float32)
+        if repeat_noise:
+            latents = latents[0:1].repeat(batch_size, 1, 1, 1)
+            original_noise = latents.clone()
+        latents = (latents * scheduler.init_noise_sigma).contiguous()
+
+        if python_loop:
+            out = self._sample_python(scheduler, latents, rgb, return_all_latents)
+        else:
+            out = self._sample_native(scheduler, latents, rgb, return_all_latents)
+        if return_all_latents:
+            return out
+        if repeat_noise:
+            return out, original_noise
+        return out
+
+    def _sample_python(self, scheduler, latents, rgb, return_all):
+        all_latents = []
+        condition = torch.zeros_like(rgb)
+        n = len(scheduler.timesteps)
+        for idx, t in enumerate(scheduler.timesteps):
+            parts = [latents, rgb] + ([condition] if self.self_condition else [])
+            inputs = torch.cat(parts, dim=1).to(self.unet_dtype)
+            noise_pred = self.unet_model(inputs, t, encoder_hidden_states=None).sample
+            if self.self_condition:
+                condition = scheduler.step(noise_pred, t, latents).pred_original_sample
+            if idx == n - 1:
+                latents = scheduler.step(noise_pred, t, latents).pred_original_sample
+            else:
+                latents = scheduler.step(noise_pred, t, latents).prev_sample
+            if return_all:
+                all_latents.append(latents)
+        return torch.cat(all_latents, dim=0) if return_all else latents
+
+    def _loop_cfg(self, scheduler):
+        ts = scheduler.timesteps_host()
+        n = len(ts)
+        coef = np.ascontiguousarray(scheduler.coefficient_table(), dtype=np.float32)
+        c_ts = (C.c_int64 * n)(*ts)
+        cfg = _lib.SampleCfg()
+        cfg.n_steps = n
+        cfg.timesteps = c_ts
+        cfg.coef = coef.ctypes.data_as(C.POINTER(C.c_float))
+        cfg.prediction_type = _lib.PRED[scheduler.prediction_type]
+        cfg.clip_sample = int(bool(scheduler.clip_sample))
+        cfg.clip_sample_range = float(scheduler.clip_sample_range)
+        cfg.self_condition = int(self.self_condition)
+        return cfg, (c_ts, coef)
+
+    def _sample_native(self, scheduler, latents, rgb, return_all, inpaint=None):
+        if scheduler.thresholding:
+            raise NotImplementedError
+        cfg, keep = self._loop_cfg(scheduler)
+        B, _, L, _ = rgb.shape
+        lat = latents.clone()
+        allv = torch.empty((cfg.n_steps * B, 4, L, L), device=rgb.device) if return_all else None
+        if inpaint is not None:
+            known, z0, noise, paste = inpaint
+            cfg.known_dev = known.data_ptr()
+            cfg.z0_dev = z0.data_ptr()
+            cfg.noise_dev = noise.data_ptr()
+            cfg.paste_coef = paste.ctypes.data_as(C.POINTER(C.c_float))
+        with torch.cuda.device(rgb.device):
+            _lib.check(_lib.lib().ldmseg_sample_loop(self.unet_model._h, C.byref(cfg), _lib.ptr(lat), _lib.ptr(rgb), B, L,
+                                                     _lib.ptr(allv), _lib.stream_ptr(rgb.device)), "ldmseg_sample_loop")
+        del keep
+        return allv if return_all else lat
+
+    # ------------------------------------------------------------------ inpainting (build-defined)
+    @torch.no_grad()
+    def sample_inpaint(self, prompts, known_mask: torch.Tensor, known_latents: torch.Tensor,
+                       num_inference_steps: int = 50, seed: Optional[int] = None,
+                       rgb_latents: Optional[torch.Tensor] = None, scheduler=None) -> torch.Tensor:
+        """Mask-inpainting DDIM sampling (absent from the reference).  ``known_mask``
+        bool [B,1,L,L], True = latent given (convention of trainers_ldm_cond.py:613-615);
+        ``known_latents`` = scaling_factor * vae_semseg.encode(partial).mode().  After every step
+        the known region is replaced by the known latents re-noised to the next timestep with the
+        same fixed noise; the final step pastes them clean."""
+        if scheduler is None:
+            scheduler = self.noise_scheduler
+            scheduler.set_timesteps_inference(num_inference_steps)
+        rgb = _lib.require_cuda_f32(rgb_latents, "rgb_latents")
+        B, _, L, _ = rgb.shape
+        noise = self.draw_noise(len(prompts), L, seed).to(rgb.device).contiguous()
+        z0 = _lib.require_cuda_f32(known_latents, "known_latents")
+        known = known_mask.to(device=rgb.device).reshape(B, 1, L, L).to(torch.uint8).contiguous()
+        ts = scheduler.timesteps_host()
+        paste = np.zeros((len(ts), 2), dtype=np.float32)
+        for i in range(len(ts)):
+            if i == len(ts) - 1:
+                paste[i] = (1.0, 0.0)
+            else:
+                a = scheduler.alphas_cumprod[ts[i + 1]]
+                paste[i] = (float(a ** 0.5), float((1 - a) ** 0.5))
+        latents = (noise * scheduler.init_noise_sigma).contiguous()
+        return self._sample_native(scheduler, latents, rgb, False, inpaint=(known, z0, noise, paste))
+
+    # ------------------------------------------------------------------ multi-GPU
+    @torch.no_grad()
+    def sample_sharded(self, prompts, num_inference_steps: int = 50, seed: Optional[int] = None,
+                       rgb_latents: Optional[torch.Tensor] = None, scheduler=None, noise_mode: str = "reference",
+                       group=None) -> torch.Tensor:
+        """Data-parallel sampling of a GLOBAL batch: rank r owns images [r*B/W, (r+1)*B/W).
+        ``rgb_latents`` is this rank's shard [B/W,4,L,L] (or the global batch on any device, from
+        which the shard is sliced).  noise_mode 'reference': every rank seeds identically and draws
+        randn(B/W) (what the reference's per-rank sample() does); 'global': one randn(B) draw,
+        sliced.  Returns the all-gathered latents [B,4,L,L] on every rank (RCCL over xGMI)."""
+        import torch.distributed as dist
+        W = dist.get_world_size(group) if dist.is_initialized() else 1
+        r = dist.get_rank(group) if dist.is_initialized() else 0
+        B = len(prompts)
+        if B % W:
+            raise ValueError("global batch must divide by world size")
+        per = B // W
+        if rgb_latents.shape[0] == B and W > 1:
+            rgb_latents = rgb_latents[r * per:(r + 1) * per]
+        L = rgb_latents.shape[-1]
+        if noise_mode == "reference":
+            noise = self.draw_noise(per, L, seed)
+        elif noise_mode == "global":
+            noise = self.draw_noise(B, L, seed)[r * per:(r + 1) * per]
+        else:
+            raise ValueError(noise_mode)
+        local = self.sample(prompts[r * per:(r + 1) * per], num_inference_steps, seed=seed,
+                            rgb_latents=rgb_latents.to(self.device), scheduler=scheduler, latents=noise)
+        if W == 1:
+            return local
+        out = torch.empty((B,) + tuple(local.shape[1:]), device=local.device, dtype=local.dtype)
+        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+        return out
+
+    # ------------------------------------------------------------------ VAE side
+    @torch.no_grad()
+    def decode_latents(self, latents: torch.Tensor, return_logits: bool = False, threshold_output: bool = False,
+                       rgb_latents=None, weight_dtype: torch.dtype = torch.float32, mask_th: float = 0.5,
+                       ignore_label: int = 0):
+        """:397-442.  The 1/scaling_factor multiply is fused into the decoder's input packing."""
+        images = self.vae_semseg.decode(latents, z_scale=1.0 / self.vae_semseg.scaling_factor).float()
+        if return_logits:
+            return images
+        predictions = torch.argmax(images, dim=1)
+        if threshold_output:
+            probs = torch.softmax(images, dim=1).max(dim=1)[0]
+            predictions[probs < mask_th] = ignore_label
+        return predictions
+
+    @torch.no_grad()
+    def encode_inputs(self, images: torch.Tensor, sample_posterior: bool = False, encode_func=None,
+                      scaling_factor: Optional[float] = None, generator=None):
+        """Segmentation side of :335-394: bit maps in [0,1] -> 2x-1 -> seg-VAE -> latents * scaling."""
+        if scaling_factor is None:
+            scaling_factor = self.vae_semseg.scaling_factor
+        mom = self.vae_semseg.encode_moments(images, in_mul=2.0, in_add=-1.0)      # images = 2*images - 1 (:369)
+        from ..models.vae import DiagonalGaussianDistribution
+        dist_ = DiagonalGaussianDistribution(mom)
+        mean = dist_.mode()
+        latents = dist_.sample(generator) if sample_posterior else mean.clone()
+        return latents * scaling_factor, mean * scaling_factor

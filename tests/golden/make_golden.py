@@ -1,0 +1,196 @@
+"""Generate golden vectors by IMPORTING the reference (runs only where /root/reference exists).
+
+    python tests/golden/make_golden.py
+
+Writes small .npz fixtures next to this file.  Nothing from the reference is copied: the
+script stubs the packages the reference imports at module level but that are absent here
+(detectron2, easydict, diffusers - SURVEY.md App. C), imports
+``ldmseg.schedulers.ddim_scheduler.DDIMNoiseScheduler`` and ``ldmseg.models.vae.GeneralVAESeg``
+and records their outputs on seeded inputs.  Weights for the seg-VAE come from this
+repository's deterministic generator (ldmseg_amd.weights) loaded into the reference module
+with ``load_state_dict(strict=True)``.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.normpath(os.path.join(HERE, "..", ".."))
+REF = "/root/reference"
+
+BASE_SCHED = dict(prediction_type="epsilon", beta_schedule="scaled_linear", num_train_timesteps=1000,
+                  beta_start=0.00085, beta_end=0.012, steps_offset=1, clip_sample=False,
+                  set_alpha_to_one=False, thresholding=False, dynamic_thresholding_ratio=0.995,
+                  clip_sample_range=1.0, sample_max_value=1.0, weight="none", max_snr=5.0)   # base.yaml:48-62
+
+
+def stub_modules():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+    dummy = type("Dummy", (), {})
+    import transformers  # noqa: F401  (must be imported before any torchvision stub)
+    mod("detectron2"); mod("detectron2.utils")
+    mod("detectron2.utils.visualizer", Visualizer=dummy, _PanopticPrediction=dummy, ColorMode=dummy,
+        _OFF_WHITE=None, _create_text_labels=None)
+    mod("easydict", EasyDict=dict)
+    mod("diffusers", AutoencoderKL=type("AutoencoderKL", (torch.nn.Module,), {}),
+        UNet2DConditionModel=type("UNet2DConditionModel", (torch.nn.Module,), {}))
+    mod("diffusers.models")
+    mod("diffusers.models.unet_2d_blocks", UNetMidBlock2D=dummy)
+    mod("diffusers.training_utils", EMAModel=dummy)
+
+
+def scheduler_golden(DDIM):
+    out = {}
+    s = DDIM(**BASE_SCHED)
+    out["betas"] = s.betas.numpy()
+    out["alphas_cumprod"] = s.alphas_cumprod.numpy()
+    out["final_alpha_cumprod"] = np.float32(s.final_alpha_cumprod)
+    out["timesteps_default"] = s.timesteps.numpy()
+    for n in (10, 50, 30, 7, 1000):
+        s.set_timesteps_inference(n)
+        out[f"timesteps_{n}"] = s.timesteps.numpy()
+    s.set_timesteps_inference(50, tmin=500)
+    out["timesteps_50_tmin500"] = s.timesteps.numpy()
+    for mode in ("none", "max_clamp_snr", "linear", "fixed"):
+        out[f"weights_{mode}"] = DDIM(**{**BASE_SCHED, "weight": mode}).weights.numpy().astype(np.float32)
+    for sched in ("linear", "squaredcos_cap_v2", "sigmoid"):
+        out[f"alphas_cumprod_{sched}"] = DDIM(**{**BASE_SCHED, "beta_schedule": sched}).alphas_cumprod.numpy()
+    out["alphas_cumprod_one"] = np.float32(DDIM(**{**BASE_SCHED, "set_alpha_to_one": True}).final_alpha_cumprod)
+
+    g = torch.Generator().manual_seed(0)
+    eps = torch.randn((1, 4, 8, 8), generator=g)
+    x = torch.randn((1, 4, 8, 8), generator=g)
+    out["step_eps"] = eps.numpy()
+    out["step_x"] = x.numpy()
+    for pt in ("epsilon", "sample", "v_prediction"):
+        for clip in (False, True):
+            for ucmo in (False, True):
+                s = DDIM(**{**BASE_SCHED, "prediction_type": pt, "clip_sample": clip})
+                s.set_timesteps_inference(50)
+                prev, x0 = [], []
+                for t in s.timesteps:
+                    o = s.step(eps, t, x, use_clipped_model_output=ucmo)
+                    prev.append(o.prev_sample.numpy())
+                    x0.append(o.pred_original_sample.numpy())
+                key = f"{pt}_clip{int(clip)}_ucmo{int(ucmo)}"
+                out[f"step_prev_{key}"] = np.stack(prev)
+                out[f"step_x0_{key}"] = np.stack(x0)
+    # per-step coefficients exactly as step() forms them (ddim_scheduler.py:231-267)
+    s = DDIM(**BASE_SCHED)
+    s.set_timesteps_inference(50)
+    coef = []
+    for t in s.timesteps:
+        t = int(t)
+        pt_ = t - 1000 // 50
+        a = s.alphas_cumprod[t]
+        ap = s.alphas_cumprod[pt_] if pt_ >= 0 else s.final_alpha_cumprod
+        coef.append([float(a ** 0.5), float((1 - a) ** 0.5), float(ap ** 0.5), float((1 - ap) ** 0.5)])
+    out["coef_50"] = np.asarray(coef, dtype=np.float32)
+    # add_noise / remove_noise with per-sample timesteps
+    x0 = torch.arange(48, dtype=torch.float32).reshape(3, 4, 2, 2) / 10
+    noise = torch.randn((3, 4, 2, 2), generator=g)
+    tt = torch.tensor([0, 500, 999])
+    out["an_x0"] = x0.numpy(); out["an_noise"] = noise.numpy(); out["an_t"] = tt.numpy()
+    noisy = s.add_noise(x0, noise.clone(), tt)
+    out["an_out"] = noisy.numpy()
+    out["an_out_scale"] = s.add_noise(x0, noise.clone(), tt, scale=0.5).numpy()
+    out["rn_out"] = s.remove_noise(noisy, noise, tt).numpy()
+    np.savez_compressed(os.path.join(HERE, "scheduler.npz"), **out)
+    print("scheduler.npz:", len(out), "arrays")
+
+
+def vae_golden(GeneralVAESeg):
+    sys.path.insert(0, os.path.join(ROOT, "latent-diffusion-segmentation_amd"))
+    from ldmseg_amd import weights
+    kw = dict(in_channels=7, int_channels=256, out_channels=128, block_out_channels=[32, 64, 128, 256],
+              latent_channels=4, num_latents=2, num_upscalers=2, upscale_channels=256, norm_num_groups=32,
+              scaling_factor=0.2, parametrization="gaussian", act_fn="none", clamp_output=False,
+              freeze_codebook=False, num_mid_blocks=0, fuse_rgb=False, resize_input=False, skip_encoder=False)
+    ref = GeneralVAESeg(**kw).eval()
+    sd = weights.generate(weights.vae_schema(), seed=7, norm_keys=weights.VAE_NORM_KEYS)
+    ref.load_state_dict(sd, strict=True)
+    out = {"n_params": np.int64(sum(p.numel() for p in ref.parameters()))}
+    g = torch.Generator().manual_seed(11)
+    ids = torch.randint(0, 128, (2, 32, 32), generator=g)
+    bits = torch.stack([(ids >> i) % 2 for i in range(7)], dim=1).float()
+    bits[:, :, :4, :4] = 0.5                       # a void patch (coco.py:377-382 fill value)
+    x = 2.0 * bits - 1.0
+    with torch.no_grad():
+        post = ref.encode(x).latent_dist
+        out["enc_x"] = x.numpy()
+        out["enc_moments"] = post.parameters.numpy()
+        out["enc_mode"] = post.mode().numpy()
+        gz = torch.Generator().manual_seed(5)
+        noise = torch.randn((2, 4, 4, 4), generator=gz)
+        out["enc_noise"] = noise.numpy()
+        out["enc_sample"] = (post.mean + post.std * noise).numpy()
+        z = torch.randn((1, 4, 4, 4), generator=g) * 1.5
+        out["dec_z"] = z.numpy()
+        out["dec_logits_4L"] = ref.decode(z, interpolate=False).numpy()
+        out["dec_logits_8L"] = ref.decode(z, interpolate=True).numpy()
+        h = ref.decoder[0](z)
+        out["dec_after_conv_in"] = h.numpy()
+        h = ref.decoder[2](h)
+        out["dec_after_convt2"] = h.numpy()
+        h = ref.decoder[4](ref.decoder[3](h))
+        out["dec_after_ln_silu"] = h.numpy()
+        fw = ref(x, sample_posterior=False)
+        out["fwd_sample"] = fw.sample.numpy()
+    out["attrs"] = np.asarray([ref.downsample_factor, ref.interpolation_factor, ref.num_latents], dtype=np.int64)
+    np.savez_compressed(os.path.join(HERE, "vae.npz"), **out)
+    print("vae.npz:", {k: v.shape for k, v in out.items() if hasattr(v, "shape")})
+
+
+def loop_golden(DDIM):
+    """TrainerDiffusion.sample cannot be imported (wandb/CUDA); pin the loop by running the
+    REFERENCE scheduler object inside a transcription of its control flow
+    (trainers_ldm_cond.py:1121-1159) with a fixed stand-in epsilon network."""
+    g = torch.Generator().manual_seed(3)
+    wmix = torch.randn((4, 12, 3, 3), generator=g) * 0.2
+
+    def eps_net(inp, t):
+        return torch.tanh(torch.nn.functional.conv2d(inp, wmix, padding=1)) * (1.0 + float(t) / 1000.0)
+
+    out = {"wmix": wmix.numpy()}
+    for n in (10, 50):
+        s = DDIM(**BASE_SCHED)
+        s.set_timesteps_inference(n)
+        rgb = 0.18215 * torch.randn((2, 4, 8, 8), generator=torch.Generator().manual_seed(1234))
+        latents = torch.randn((2, 4, 8, 8), generator=torch.Generator().manual_seed(42)) * s.init_noise_sigma
+        cond = torch.zeros_like(rgb)
+        for i, t in enumerate(s.timesteps):
+            eps = eps_net(torch.cat([latents, rgb, cond], dim=1), t)
+            cond = s.step(eps, t, latents).pred_original_sample
+            if i == len(s.timesteps) - 1:
+                latents = s.step(eps, t, latents).pred_original_sample
+            else:
+                latents = s.step(eps, t, latents).prev_sample
+        out[f"rgb_{n}"] = rgb.numpy()
+        out[f"final_{n}"] = latents.numpy()
+    np.savez_compressed(os.path.join(HERE, "sample_loop.npz"), **out)
+    print("sample_loop.npz ok")
+
+
+def main():
+    if not os.path.isdir(REF):
+        print("reference not present; nothing to do")
+        return
+    stub_modules()
+    sys.path.insert(0, REF)
+    from ldmseg.schedulers.ddim_scheduler import DDIMNoiseScheduler
+    from ldmseg.models.vae import GeneralVAESeg
+    torch.manual_seed(0)
+    scheduler_golden(DDIMNoiseScheduler)
+    vae_golden(GeneralVAESeg)
+    loop_golden(DDIMNoiseScheduler)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,202 @@
+"""GPU parity, per kernel: every gfx950 kernel is driven through the C ABI (ldmseg_op_*) and compared
+with the torch-CPU fp32 op the reference executes at that point (the oracle's arithmetic primitives).
+fp32 kernels must meet the north-star 1e-3 max-norm bound; bf16 kernels a bf16-rounding bound."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+F32, BF16 = 0, 1
+TOL = {F32: 1e-3, BF16: 3e-2}
+
+
+@pytest.fixture(scope="module")
+def L():
+    from ldmseg_amd import _lib
+    return _lib
+
+
+def dev(t):
+    return t.to("cuda", torch.float32).contiguous() if t is not None else None
+
+
+def P(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def bf16_round(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("case", [
+    # B, Ci, Ci2, H, W, Co, k, stride, up
+    (2, 64, 0, 16, 16, 320, 3, 1, 0),
+    (1, 320, 0, 16, 16, 320, 3, 1, 0),
+    (2, 128, 0, 16, 16, 64, 3, 2, 0),
+    (1, 64, 0, 8, 8, 128, 3, 1, 1),
+    (1, 128, 64, 8, 8, 160, 3, 1, 0),      # channel concat
+    (1, 128, 64, 8, 8, 96, 1, 1, 0),       # conv_shortcut on a concat
+    (3, 12, 0, 8, 8, 320, 3, 1, 0),        # conv_in style (tiny Cin, padded)
+    (1, 320, 0, 8, 8, 4, 3, 1, 0),         # conv_out style (tiny Cout)
+    (1, 64, 0, 5, 7, 32, 3, 1, 0),         # ragged M (35 rows)
+    (2, 192, 0, 12, 12, 640, 1, 1, 0),
+])
+def test_conv2d(L, dt, case):
+    B, Ci, Ci2, H, W, Co, k, stride, up = case
+    g = torch.Generator().manual_seed(hash(case) & 0xffff)
+    x = torch.randn(B, Ci, H, W, generator=g)
+    x2 = torch.randn(B, Ci2, H, W, generator=g) if Ci2 else None
+    w = torch.randn(Co, Ci + Ci2, k, k, generator=g) / ((Ci + Ci2) * k * k) ** 0.5
+    b = torch.randn(Co, generator=g)
+    xin = torch.cat([x, x2], 1) if Ci2 else x
+    if dt == BF16:
+        xin_r, w_r = bf16_round(xin), bf16_round(w)
+    else:
+        xin_r, w_r = xin, w
+    if up:
+        xin_r = F.interpolate(xin_r, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(xin_r, w_r, b, stride=stride, padding=k // 2)
+    out = torch.empty(ref.shape, device="cuda")
+    r = L.lib().ldmseg_op_conv2d(P(dev(x)), P(dev(x2)), P(dev(w)), P(dev(b)), B, Ci, Ci2, H, W, Co, k, stride, up, dt,
+                                 P(out), None)
+    assert r == 0
+    torch.cuda.synchronize()
+    # inputs were rounded identically, so even bf16 only differs by accumulation order
+    assert rel_err(out, ref) < (1e-3 if dt == BF16 else 2e-5), case
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("case", [
+    # M, K, N, geglu, silu, resid, rowbias(rows_per_image), splits
+    (256, 320, 960, 0, 0, False, 0, 1),
+    (300, 128, 320, 0, 0, True, 0, 1),
+    (256, 64, 640, 0, 1, False, 64, 1),
+    (128, 320, 2560, 1, 0, False, 0, 1),     # GEGLU: [M, 8C] -> [M, 4C]
+    (96, 1280, 320, 0, 0, True, 0, 1),
+    (64, 2304, 1280, 0, 0, True, 16, 3),     # split-K
+    (1, 64, 32, 0, 0, False, 0, 1),
+])
+def test_linear(L, dt, case):
+    M, K, N, geglu, silu, use_res, rpi, splits = case
+    g = torch.Generator().manual_seed(M * 7 + N)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    nout = N // 2 if geglu else N
+    res = torch.randn(M, nout, generator=g) if use_res else None
+    rb = torch.randn(M // rpi, N, generator=g) if rpi else None
+    xr, wr = (bf16_round(x), bf16_round(w)) if dt == BF16 else (x, w)
+    y = xr @ wr.t() + b
+    if rb is not None:
+        y = y + rb.repeat_interleave(rpi, 0)
+    if geglu:
+        a, gate = y.chunk(2, -1)
+        y = a * F.gelu(gate)
+    if res is not None:
+        y = y + (bf16_round(res) if dt == BF16 else res)
+    if silu:
+        y = F.silu(y)
+    out = torch.empty(M, nout, device="cuda")
+    r = L.lib().ldmseg_op_linear(P(dev(x)), P(dev(w)), P(dev(b)), P(dev(res)), P(dev(rb)), rpi if rpi else M, M, K, N,
+                                 geglu, silu, splits, dt, P(out), None)
+    assert r == 0
+    torch.cuda.synchronize()
+    # the kernel output itself is rounded to the storage type
+    assert rel_err(out, y) < (8e-3 if dt == BF16 else 2e-5), case
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("case", [
+    # B, C, C2, HW, eps, silu
+    (2, 320, 0, 256, 1e-5, 1),
+    (1, 640, 320, 64, 1e-5, 1),       # concat, group straddles the source boundary (cpg = 30)
+    (1, 1280, 640, 16, 1e-5, 1),      # cpg = 60
+    (3, 256, 0, 1024, 1e-6, 1),       # seg-VAE GN (cpg = 8)
+    (1, 2560, 0, 4, 1e-5, 0),         # 2x2 map, widest concat
+    (2, 1280, 0, 1, 1e-6, 0),         # single pixel
+])
+def test_groupnorm(L, dt, case):
+    B, Cc, C2, HW, eps, silu = case
+    g = torch.Generator().manual_seed(Cc + HW)
+    x = torch.randn(B, Cc, HW, generator=g) * 2 + 0.5
+    x2 = torch.randn(B, C2, HW, generator=g) - 1.0 if C2 else None
+    gamma = 1 + 0.1 * torch.randn(Cc + C2, generator=g)
+    beta = 0.1 * torch.randn(Cc + C2, generator=g)
+    xin = torch.cat([x, x2], 1) if C2 else x
+    if dt == BF16:
+        xin = bf16_round(xin)
+    ref = F.group_norm(xin, 32, gamma, beta, eps)
+    if silu:
+        ref = F.silu(ref)
+    out = torch.empty(B, Cc + C2, HW, device="cuda")
+    r = L.lib().ldmseg_op_groupnorm(P(dev(x)), P(dev(x2)), P(dev(gamma)), P(dev(beta)), B, Cc, C2, HW, eps, silu, dt,
+                                    P(out), None)
+    assert r == 0
+    torch.cuda.synchronize()
+    assert rel_err(out, ref) < (8e-3 if dt == BF16 else 5e-5), case
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("M,Cc,eps,silu", [(77, 320, 1e-5, 0), (64, 640, 1e-5, 0), (33, 1280, 1e-5, 0), (50, 256, 1e-6, 1)])
+def test_layernorm(L, dt, M, Cc, eps, silu):
+    g = torch.Generator().manual_seed(M + Cc)
+    x = torch.randn(M, Cc, generator=g) * 3 + 1
+    gamma = 1 + 0.1 * torch.randn(Cc, generator=g)
+    beta = 0.1 * torch.randn(Cc, generator=g)
+    xin = bf16_round(x) if dt == BF16 else x
+    ref = F.layer_norm(xin, (Cc,), gamma, beta, eps)
+    if silu:
+        ref = F.silu(ref)
+    out = torch.empty(M, Cc, device="cuda")
+    assert L.lib().ldmseg_op_layernorm(P(dev(x)), P(dev(gamma)), P(dev(beta)), M, Cc, eps, silu, dt, P(out), None) == 0
+    torch.cuda.synchronize()
+    assert rel_err(out, ref) < (8e-3 if dt == BF16 else 2e-5)
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("B,N,Cc", [(1, 256, 320), (2, 64, 320), (1, 1024, 320), (1, 256, 640), (2, 4, 1280),
+                                    (1, 64, 1280), (1, 100, 640), (1, 320, 1280), (1, 4096, 320)])
+def test_attention(L, dt, B, N, Cc):
+    g = torch.Generator().manual_seed(N + Cc)
+    qkv = torch.randn(B, N, 3 * Cc, generator=g)
+    qkv[:, :, :Cc] *= 2.0                  # sharper softmax
+    qkv[0, N // 2, Cc:Cc + 40] += 6.0      # one dominant key (forces the running-max rescale path)
+    src = bf16_round(qkv) if dt == BF16 else qkv
+    q, k, v = src.chunk(3, -1)
+    d = Cc // 8
+    q = q.view(B, N, 8, d).transpose(1, 2)
+    k = k.view(B, N, 8, d).transpose(1, 2)
+    v = v.view(B, N, 8, d).transpose(1, 2)
+    ref = (torch.softmax((q.double() @ k.double().transpose(-1, -2)) * d ** -0.5, -1) @ v.double())
+    ref = ref.transpose(1, 2).reshape(B, N, Cc).float()
+    out = torch.empty(B, N, Cc, device="cuda")
+    assert L.lib().ldmseg_op_attention(P(dev(qkv)), B, N, Cc, 8, dt, P(out), None) == 0
+    torch.cuda.synchronize()
+    assert rel_err(out, ref) < (1.5e-2 if dt == BF16 else 2e-5)
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
+def test_convt2_and_bilinear(L, dt):
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 256, 6, 6, generator=g)
+    w = torch.randn(256, 256, 2, 2, generator=g) / 16
+    b = torch.randn(256, generator=g)
+    xr, wr = (bf16_round(x), bf16_round(w)) if dt == BF16 else (x, w)
+    ref = F.conv_transpose2d(xr, wr, b, stride=2)
+    out = torch.empty(ref.shape, device="cuda")
+    assert L.lib().ldmseg_op_convt2(P(dev(x)), P(dev(w)), P(dev(b)), 2, 256, 6, 6, 256, dt, P(out), None) == 0
+    torch.cuda.synchronize()
+    assert rel_err(out, ref) < (8e-3 if dt == BF16 else 2e-5)
+    y = torch.randn(2, 128, 5, 9, generator=g)
+    yr = bf16_round(y) if dt == BF16 else y
+    ref = F.interpolate(yr, scale_factor=2, mode="bilinear", align_corners=False)
+    out = torch.empty(ref.shape, device="cuda")
+    assert L.lib().ldmseg_op_bilinear2x(P(dev(y)), 2, 128, 5, 9, dt, P(out), None) == 0
+    torch.cuda.synchronize()
+    assert rel_err(out, ref) < 1e-5

@@ -1,0 +1,213 @@
+"""GPU parity of the whole path through the C ABI: scheduler kernels (bit-exact against the
+reference-generated goldens), seg-VAE and UNet against the oracle, the sampling loop, the
+build-defined inpainting sampler, and size-independent properties at the BASELINE size."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import ddim as o_ddim, sample as o_sample, unet as o_unet, vae as o_vae
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def sched(sched_kw):
+    from ldmseg_amd.schedulers import DDIMNoiseScheduler
+    s = DDIMNoiseScheduler(**sched_kw)
+    s.set_timesteps_inference(50)
+    return s
+
+
+# ------------------------------------------------------------------ scheduler (bit-exact)
+@pytest.mark.parametrize("pt", ["epsilon", "sample", "v_prediction"])
+@pytest.mark.parametrize("clip", [False, True])
+@pytest.mark.parametrize("ucmo", [False, True])
+def test_step_bit_exact_vs_reference_golden(golden, sched_kw, pt, clip, ucmo):
+    from ldmseg_amd.schedulers import DDIMNoiseScheduler
+    g = golden("scheduler.npz")
+    s = DDIMNoiseScheduler(**{**sched_kw, "prediction_type": pt, "clip_sample": clip})
+    s.set_timesteps_inference(50, device=DEV)          # GPU-resident timesteps, like compute_pq (:1211-1212)
+    eps = torch.from_numpy(g["step_eps"]).to(DEV)
+    x = torch.from_numpy(g["step_x"]).to(DEV)
+    key = f"{pt}_clip{int(clip)}_ucmo{int(ucmo)}"
+    for i, t in enumerate(s.timesteps):
+        o = s.step(eps, t, x, use_clipped_model_output=ucmo)
+        assert list(o.keys()) == ["prev_sample", "pred_original_sample"]
+        assert np.array_equal(o.prev_sample.cpu().numpy(), g[f"step_prev_{key}"][i]), (key, i)
+        assert np.array_equal(o["pred_original_sample"].cpu().numpy(), g[f"step_x0_{key}"][i]), (key, i)
+    o = s.step(eps, 999, x)                              # python-int timestep gives the same result
+    assert np.array_equal(o.prev_sample.cpu().numpy(), g[f"step_prev_{pt}_clip{int(clip)}_ucmo0"][0])
+
+
+def test_noise_ops_bit_exact(golden, sched):
+    g = golden("scheduler.npz")
+    x0, noise = torch.from_numpy(g["an_x0"]).to(DEV), torch.from_numpy(g["an_noise"]).to(DEV)
+    t = torch.from_numpy(g["an_t"])
+    assert np.array_equal(sched.add_noise(x0, noise, t).cpu().numpy(), g["an_out"])
+    assert np.array_equal(sched.add_noise(x0, noise, t, scale=0.5).cpu().numpy(), g["an_out_scale"])
+    noisy = torch.from_numpy(g["an_out"]).to(DEV)
+    assert np.array_equal(sched.remove_noise(noisy, noise, t.to(DEV)).cpu().numpy(), g["rn_out"])
+
+
+# ------------------------------------------------------------------ seg-VAE
+@pytest.fixture(scope="module", params=["fp32", "bf16"])
+def vae(request, vae_sd):
+    from ldmseg_amd.models import GeneralVAESeg
+    return GeneralVAESeg(vae_sd, scaling_factor=0.2, device=DEV, compute_dtype=request.param), request.param
+
+
+def test_vae_vs_reference_golden(golden, vae):
+    v, mode = vae
+    tol = 1e-3 if mode == "fp32" else 4e-2
+    g = golden("vae.npz")
+    assert v.num_parameters == 2023208
+    assert (v.downsample_factor, v.interpolation_factor, v.num_latents) == (8, 2, 2)
+    x = torch.from_numpy(g["enc_x"]).to(DEV)
+    post = v.encode(x).latent_dist
+    assert rel_err(post.parameters, g["enc_moments"]) < tol
+    assert rel_err(post.mode(), g["enc_mode"]) < tol
+    z = torch.from_numpy(g["dec_z"]).to(DEV)
+    assert rel_err(v.decode(z, interpolate=False), g["dec_logits_4L"]) < tol
+    assert rel_err(v.decode(z, interpolate=True), g["dec_logits_8L"]) < tol
+    fw = v(x, sample_posterior=False)
+    assert rel_err(fw.sample, g["fwd_sample"]) < tol
+
+
+def test_vae_vs_oracle_larger(vae, vae_sd):
+    v, mode = vae
+    tol = 1e-3 if mode == "fp32" else 4e-2
+    g = torch.Generator().manual_seed(21)
+    z = torch.randn(2, 4, 16, 16, generator=g)
+    with torch.no_grad():
+        ref = o_vae.decode(vae_sd, z * (1 / 0.2), interpolate=True)
+    out = v.decode(z.to(DEV), interpolate=True, z_scale=1 / 0.2)
+    assert out.shape == (2, 128, 128, 128)
+    assert rel_err(out, ref) < tol
+    bits = (torch.rand(2, 7, 64, 64, generator=g) > 0.5).float()
+    with torch.no_grad():
+        refm = o_vae.encode_moments(vae_sd, 2 * bits - 1)
+    mom = v.encode_moments(bits.to(DEV), in_mul=2.0, in_add=-1.0)
+    assert rel_err(mom, refm) < tol
+    noise = torch.randn(2, 4, 8, 8, generator=g)
+    from ldmseg_amd import _lib
+    import ctypes as C
+    out = torch.empty(2, 4, 8, 8, device=DEV)
+    _lib.check(_lib.lib().ldmseg_vae_posterior(_lib.ptr(mom), _lib.ptr(noise.to(DEV)), 1.0, 2, 8, _lib.ptr(out), None))
+    torch.cuda.synchronize()
+    mean, logvar = mom.cpu().chunk(2, 1)
+    assert rel_err(out, mean + torch.exp(0.5 * logvar.clamp(-30, 20)) * noise) < 1e-5
+
+
+# ------------------------------------------------------------------ UNet
+@pytest.fixture(scope="module")
+def unets(unet_sd):
+    from ldmseg_amd.models import UNet
+    return {m: UNet(unet_sd, in_channels=12, device=DEV, compute_dtype=m) for m in ("fp32", "bf16")}
+
+
+def test_unet_structure(unets):
+    u = unets["fp32"]
+    assert u.num_parameters == 815_556_484
+    assert u.config.block_out_channels == [320, 640, 1280, 1280]
+    assert u.workspace_bytes(1, 16) > 0
+    with pytest.raises(RuntimeError):
+        u(torch.zeros(1, 12, 16, 16), 10)            # CPU tensor: no fallback
+    with pytest.raises(NotImplementedError):
+        u(torch.zeros(1, 12, 16, 16, device=DEV), 10, encoder_hidden_states=torch.zeros(1, 77, 768))
+
+
+@pytest.mark.parametrize("B,Ls,t", [(1, 16, 999), (2, 16, [19, 500]), (1, 32, 259)])
+def test_unet_fp32_parity_vs_oracle(unets, unet_sd, B, Ls, t):
+    """north star: within 1e-3 rel (fp32) of the PyTorch-CPU forward on the same inputs."""
+    g = torch.Generator().manual_seed(Ls + B)
+    x = torch.randn(B, 12, Ls, Ls, generator=g)
+    tt = torch.tensor(t)
+    with torch.no_grad():
+        ref = o_unet.unet_forward(unet_sd, x, tt)
+    out = unets["fp32"](x.to(DEV), tt.to(DEV) if tt.dim() else tt, encoder_hidden_states=None).sample
+    assert out.shape == ref.shape
+    assert rel_err(out, ref) < 1e-3
+    outb = unets["bf16"](x.to(DEV), tt.to(DEV) if tt.dim() else tt).sample
+    assert rel_err(outb, ref) < 6e-2               # bf16 storage through 38 blocks (perf mode)
+    rl2 = float((outb.cpu() - ref).norm() / ref.norm())
+    assert rl2 < 3e-2
+
+
+def test_unet_forward_parts_equals_concat(unets):
+    u = unets["fp32"]
+    g = torch.Generator().manual_seed(3)
+    lat, rgb, cond = (torch.randn(2, 4, 16, 16, generator=g).to(DEV) for _ in range(3))
+    a = u(torch.cat([lat, rgb, cond], 1), 459).sample
+    b = u.forward_parts(lat, rgb, cond, 459).sample
+    assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------ sampling loop
+def test_sample_native_equals_python_loop(unets, vae_sd, sched_kw):
+    from ldmseg_amd.models import GeneralVAESeg
+    from ldmseg_amd.schedulers import DDIMNoiseScheduler
+    from ldmseg_amd.trainers import TrainerDiffusion
+    u = unets["fp32"]
+    tr = TrainerDiffusion(None, u, DDIMNoiseScheduler(**sched_kw))
+    rgb = (0.18215 * torch.randn(2, 4, 16, 16, generator=torch.Generator().manual_seed(1234))).to(DEV)
+    a = tr.sample(["", ""], num_inference_steps=5, seed=42, rgb_latents=rgb)
+    s = DDIMNoiseScheduler(**sched_kw)
+    s.set_timesteps_inference(5, device=DEV)
+    b = tr.sample(["", ""], num_inference_steps=5, seed=42, rgb_latents=rgb, scheduler=s, python_loop=True)
+    assert torch.equal(a, b)
+    allv = tr.sample(["", ""], num_inference_steps=5, seed=42, rgb_latents=rgb, return_all_latents=True)
+    assert allv.shape == (10, 4, 16, 16) and torch.equal(allv[-2:], a)
+    c, noise0 = tr.sample(["", ""], num_inference_steps=5, seed=42, rgb_latents=rgb, repeat_noise=True)
+    assert torch.equal(noise0[0], noise0[1])
+
+
+def test_sample_vs_oracle(unets, unet_sd, sched_kw):
+    from ldmseg_amd.schedulers import DDIMNoiseScheduler
+    from ldmseg_amd.trainers import TrainerDiffusion
+    tr = TrainerDiffusion(None, unets["fp32"], DDIMNoiseScheduler(**sched_kw))
+    rgb = 0.18215 * torch.randn(1, 4, 16, 16, generator=torch.Generator().manual_seed(1234))
+    out = tr.sample([""], num_inference_steps=4, seed=42, rgb_latents=rgb.to(DEV))
+    so = o_ddim.OracleDDIM(**sched_kw)
+    so.set_timesteps_inference(4)
+    with torch.no_grad():
+        ref = o_sample.sample(lambda inp, t: o_unet.unet_forward(unet_sd, inp, t), so, rgb, seed=42)
+    assert rel_err(out, ref) < 2e-3
+
+
+def test_inpaint_vs_oracle(unets, unet_sd, sched_kw):
+    from ldmseg_amd.schedulers import DDIMNoiseScheduler
+    from ldmseg_amd.trainers import TrainerDiffusion
+    tr = TrainerDiffusion(None, unets["fp32"], DDIMNoiseScheduler(**sched_kw))
+    g = torch.Generator().manual_seed(7)
+    rgb = 0.18215 * torch.randn(1, 4, 16, 16, generator=g)
+    z0 = 0.2 * torch.randn(1, 4, 16, 16, generator=g)
+    known = torch.rand(1, 1, 16, 16, generator=g) < 0.5
+    out = tr.sample_inpaint([""], known, z0.to(DEV), num_inference_steps=4, seed=42, rgb_latents=rgb.to(DEV))
+    so = o_ddim.OracleDDIM(**sched_kw)
+    so.set_timesteps_inference(4)
+    with torch.no_grad():
+        ref = o_sample.sample_inpaint(lambda inp, t: o_unet.unet_forward(unet_sd, inp, t), so, rgb, z0, known, seed=42)
+    assert rel_err(out, ref) < 2e-3
+    m = known.expand_as(z0)
+    assert torch.equal(out.cpu()[m], z0[m])            # the known region comes back exactly
+
+
+# ------------------------------------------------------------------ BASELINE-size properties (bf16, B=8, L=64)
+def test_full_size_properties(unets):
+    u = unets["bf16"]
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(8, 12, 64, 64, generator=g).to(DEV)
+    t = torch.tensor(499, device=DEV)
+    y1 = u(x, t).sample
+    y2 = u(x, t).sample
+    assert torch.isfinite(y1).all()
+    assert torch.equal(y1, y2)                                      # deterministic (no atomics)
+    perm = torch.tensor([3, 1, 7, 0, 2, 6, 5, 4], device=DEV)
+    yp = u(x[perm].contiguous(), t).sample
+    assert rel_err(yp, y1[perm]) < 1e-6                             # images are independent / batch-equivariant
+    y_single = u(x[2:3].contiguous(), t).sample
+    assert rel_err(y_single, y1[2:3]) < 2e-2                        # only the GN chunking differs with B
+    tt = torch.full((8,), 499, device=DEV, dtype=torch.int64)
+    assert torch.equal(u(x, tt).sample, y1)                         # [B] timesteps == broadcast scalar
