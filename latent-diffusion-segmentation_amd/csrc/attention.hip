@@ -186,8 +186,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
                              pack_bf16x2(s[a][2 * g + 1][0], s[a][2 * g + 1][1]),
                              pack_bf16x2(s[a][2 * g + 1][2], s[a][2 * g + 1][3]));
         } else {
-          pb[a] = make_uint4(__builtin_bit_cast(uint32_t, s[a][g][0]), __builtin_bit_cast(uint32_t, s[a][g][1]),
-                             __builtin_bit_cast(uint32_t, s[a][g][2]), __builtin_bit_cast(uint32_t, s[a][g][3]));
+          const float p0 = s[a][g][0], p1 = s[a][g][1], p2 = s[a][g][2], p3 = s[a][g][3];
+          pb[a] = make_uint4(f32_bits(p0), f32_bits(p1), f32_bits(p2), f32_bits(p3));
         }
       }
 #pragma unroll

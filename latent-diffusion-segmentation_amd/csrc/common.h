@@ -32,6 +32,10 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
   u += 0x7fffu + ((u >> 16) & 1u);
   return (bf16_t)(u >> 16);
 }
+// NOTE: never apply __builtin_bit_cast directly to an ext_vector element (v[i]): hipcc 7.2 then
+// reads element 0.  Go through these by-value helpers instead.
+__device__ __forceinline__ uint32_t f32_bits(float f) { return __builtin_bit_cast(uint32_t, f); }
+__device__ __forceinline__ float bits_f32(uint32_t u) { return __builtin_bit_cast(float, u); }
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
   return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
 }

@@ -12,7 +12,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.normpath(os.path.join(HERE, "..", "csrc"))
 INCLUDE = os.path.normpath(os.path.join(HERE, "..", "..", "include"))
 LIB_PATH = os.path.join(HERE, "libldmseg_hip.so")
-SOURCES = ["igemm.hip", "norm.hip", "attention.hip", "misc.hip", "engine.hip", "ops_api.hip"]
+SOURCES = ["igemm.hip", "norm.hip", "attention.hip", "misc.hip", "sched.hip", "engine.hip", "ops_api.hip"]
+EXTRA_FLAGS = {"sched.hip": ["-ffp-contract=off"]}   # bit-exact scheduler arithmetic
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 
 
@@ -44,7 +45,7 @@ def build_library(force=False, verbose=False):
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            jobs.append([hipcc] + FLAGS + ["-c", s, "-o", o])
+            jobs.append([hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:

@@ -63,8 +63,8 @@ def test_conv2d(L, dt, case):
         xin_r = F.interpolate(xin_r, scale_factor=2.0, mode="nearest")
     ref = F.conv2d(xin_r, w_r, b, stride=stride, padding=k // 2)
     out = torch.empty(ref.shape, device="cuda")
-    r = L.lib().ldmseg_op_conv2d(P(dev(x)), P(dev(x2)), P(dev(w)), P(dev(b)), B, Ci, Ci2, H, W, Co, k, stride, up, dt,
-                                 P(out), None)
+    dx, dx2, dw, db = dev(x), dev(x2), dev(w), dev(b)
+    r = L.lib().ldmseg_op_conv2d(P(dx), P(dx2), P(dw), P(db), B, Ci, Ci2, H, W, Co, k, stride, up, dt, P(out), None)
     assert r == 0
     torch.cuda.synchronize()
     # inputs were rounded identically, so even bf16 only differs by accumulation order
@@ -103,7 +103,8 @@ def test_linear(L, dt, case):
     if silu:
         y = F.silu(y)
     out = torch.empty(M, nout, device="cuda")
-    r = L.lib().ldmseg_op_linear(P(dev(x)), P(dev(w)), P(dev(b)), P(dev(res)), P(dev(rb)), rpi if rpi else M, M, K, N,
+    dx, dw, db, dres, drb = dev(x), dev(w), dev(b), dev(res), dev(rb)
+    r = L.lib().ldmseg_op_linear(P(dx), P(dw), P(db), P(dres), P(drb), rpi if rpi else M, M, K, N,
                                  geglu, silu, splits, dt, P(out), None)
     assert r == 0
     torch.cuda.synchronize()
@@ -135,8 +136,8 @@ def test_groupnorm(L, dt, case):
     if silu:
         ref = F.silu(ref)
     out = torch.empty(B, Cc + C2, HW, device="cuda")
-    r = L.lib().ldmseg_op_groupnorm(P(dev(x)), P(dev(x2)), P(dev(gamma)), P(dev(beta)), B, Cc, C2, HW, eps, silu, dt,
-                                    P(out), None)
+    dx, dx2, dg, db = dev(x), dev(x2), dev(gamma), dev(beta)
+    r = L.lib().ldmseg_op_groupnorm(P(dx), P(dx2), P(dg), P(db), B, Cc, C2, HW, eps, silu, dt, P(out), None)
     assert r == 0
     torch.cuda.synchronize()
     assert rel_err(out, ref) < (8e-3 if dt == BF16 else 5e-5), case
@@ -154,7 +155,8 @@ def test_layernorm(L, dt, M, Cc, eps, silu):
     if silu:
         ref = F.silu(ref)
     out = torch.empty(M, Cc, device="cuda")
-    assert L.lib().ldmseg_op_layernorm(P(dev(x)), P(dev(gamma)), P(dev(beta)), M, Cc, eps, silu, dt, P(out), None) == 0
+    dx, dg, db = dev(x), dev(gamma), dev(beta)
+    assert L.lib().ldmseg_op_layernorm(P(dx), P(dg), P(db), M, Cc, eps, silu, dt, P(out), None) == 0
     torch.cuda.synchronize()
     assert rel_err(out, ref) < (8e-3 if dt == BF16 else 2e-5)
 
@@ -176,7 +178,8 @@ def test_attention(L, dt, B, N, Cc):
     ref = (torch.softmax((q.double() @ k.double().transpose(-1, -2)) * d ** -0.5, -1) @ v.double())
     ref = ref.transpose(1, 2).reshape(B, N, Cc).float()
     out = torch.empty(B, N, Cc, device="cuda")
-    assert L.lib().ldmseg_op_attention(P(dev(qkv)), B, N, Cc, 8, dt, P(out), None) == 0
+    dq = dev(qkv)
+    assert L.lib().ldmseg_op_attention(P(dq), B, N, Cc, 8, dt, P(out), None) == 0
     torch.cuda.synchronize()
     assert rel_err(out, ref) < (1.5e-2 if dt == BF16 else 2e-5)
 
@@ -190,13 +193,15 @@ def test_convt2_and_bilinear(L, dt):
     xr, wr = (bf16_round(x), bf16_round(w)) if dt == BF16 else (x, w)
     ref = F.conv_transpose2d(xr, wr, b, stride=2)
     out = torch.empty(ref.shape, device="cuda")
-    assert L.lib().ldmseg_op_convt2(P(dev(x)), P(dev(w)), P(dev(b)), 2, 256, 6, 6, 256, dt, P(out), None) == 0
+    dx, dw, db = dev(x), dev(w), dev(b)
+    assert L.lib().ldmseg_op_convt2(P(dx), P(dw), P(db), 2, 256, 6, 6, 256, dt, P(out), None) == 0
     torch.cuda.synchronize()
     assert rel_err(out, ref) < (8e-3 if dt == BF16 else 2e-5)
     y = torch.randn(2, 128, 5, 9, generator=g)
     yr = bf16_round(y) if dt == BF16 else y
     ref = F.interpolate(yr, scale_factor=2, mode="bilinear", align_corners=False)
     out = torch.empty(ref.shape, device="cuda")
-    assert L.lib().ldmseg_op_bilinear2x(P(dev(y)), 2, 128, 5, 9, dt, P(out), None) == 0
+    dy = dev(y)
+    assert L.lib().ldmseg_op_bilinear2x(P(dy), 2, 128, 5, 9, dt, P(out), None) == 0
     torch.cuda.synchronize()
     assert rel_err(out, ref) < 1e-5
