@@ -1,0 +1,209 @@
+#!/usr/bin/env python
+"""Benchmark of the LDMSeg denoising path on MI355X.
+
+    python bench.py --gpus 1 --steps 50 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], per GPU): 512x512 images -> 64x64x4 latents, batch 8, bf16,
+SD-1.x UNet with the 12-channel self-conditioned conv_in and cross-attention removed, DDIM.  One
+"step" = one denoising step of the whole batch: UNet forward + DDIM update (+ self-condition
+update), run by ldmseg_sample_loop.  Inputs are resident in HBM when the timed region starts.
+`value` = images-in-flight x steps / wall seconds, summed over all ranks (weak scaling: 8 images per
+GPU, images are independent, no collective inside the loop; one RCCL all-gather of the final latents
+is timed in the separate images/s figure).  Synthetic data, deterministic random-init weights (no
+checkpoint or dataset exists offline).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "latent-diffusion-segmentation_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+SCHED_KW = dict(prediction_type="epsilon", beta_schedule="scaled_linear", num_train_timesteps=1000,
+                beta_start=0.00085, beta_end=0.012, clip_sample=False, set_alpha_to_one=False)
+FLOP_UNET_L64 = 771.4e9      # per image-step, SURVEY 8(d) / BASELINE.md section 2
+FLOP_DEC_L64 = 49.5e9        # seg-VAE decode per image
+PEAK_BF16 = 2.5e15           # dense MFMA bf16, MI355X_MICROARCH.md
+PEAK_F32 = 157.3e12
+
+
+def cpu_baseline(usd, budget_s=25.0):
+    """The oracle (a torch-CPU port of the reference path) on this host's cores: UNet forward,
+    B=1, L=64, fp32 - a bounded sample of the same workload."""
+    from oracle import unet as o_unet
+    torch.set_num_threads(os.cpu_count() or 1)
+    x = torch.randn(1, 12, 64, 64, generator=torch.Generator().manual_seed(0))
+    t = torch.tensor(499)
+    times = []
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        o_unet.unet_forward(usd, x, t)
+        first = time.perf_counter() - t0
+        spent = first
+        while spent + first < budget_s and len(times) < 5:
+            t0 = time.perf_counter()
+            o_unet.unet_forward(usd, x, t)
+            dt = time.perf_counter() - t0
+            times.append(dt)
+            spent += dt
+    per = min(times) if times else first
+    return {"value": 1.0 / per, "unit": "image-steps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle UNet forward, B=1, L=64, fp32, {1 + len(times)} forward(s), best {per:.2f}s "
+                      f"(first incl. warm-up {first:.2f}s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU")
+    ap.add_argument("--latent", type=int, default=64)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-images", action="store_true", help="skip the 50-step images/s run")
+    ap.add_argument("--profile-steps", type=int, default=3)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from ldmseg_amd import _lib, weights
+    from ldmseg_amd.models import UNet, GeneralVAESeg
+    from ldmseg_amd.schedulers import DDIMNoiseScheduler
+    from ldmseg_amd.trainers import TrainerDiffusion
+    import ctypes as C
+
+    B, L = args.batch, args.latent
+    usd = weights.generate(weights.unet_schema(12, False), seed=0)
+    vsd = weights.generate(weights.vae_schema(), seed=7, norm_keys=weights.VAE_NORM_KEYS)
+    unet = UNet(usd, in_channels=12, device=dev, compute_dtype=args.dtype)
+    vae = GeneralVAESeg(vsd, scaling_factor=0.18215, device=dev, compute_dtype=args.dtype)
+    tr = TrainerDiffusion(vae, unet, DDIMNoiseScheduler(**SCHED_KW))
+
+    rgb = (0.18215 * torch.randn(B, 4, L, L, generator=torch.Generator().manual_seed(1234 + rank))).to(dev)
+    prompts = [""] * B
+
+    def run_steps(k):
+        s = DDIMNoiseScheduler(**SCHED_KW)
+        s.set_timesteps_inference(k)
+        return tr.sample(prompts, num_inference_steps=k, seed=42, rgb_latents=rgb, scheduler=s)
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    # ---- warm-up, then exactly K timed steps bracketed by barrier + synchronize ----
+    if args.warmup > 0:
+        run_steps(args.warmup)
+    sync_all()
+    t0 = time.perf_counter()
+    lat = run_steps(args.steps)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+    assert torch.isfinite(lat).all()
+
+    # ---- images/s: 50-step DDIM + all-gather of latents + seg-VAE decode to logits ----
+    images_per_s = None
+    if not args.no_images:
+        sync_all()
+        t1 = time.perf_counter()
+        s50 = DDIMNoiseScheduler(**SCHED_KW)
+        s50.set_timesteps_inference(50)
+        if world > 1:
+            allv = tr.sample_sharded([""] * (B * world), 50, seed=42, rgb_latents=rgb, scheduler=s50)
+            mine = allv[rank * B:(rank + 1) * B]
+        else:
+            mine = tr.sample(prompts, 50, seed=42, rgb_latents=rgb, scheduler=s50)
+        logits = tr.decode_latents(mine, return_logits=True)
+        sync_all()
+        e2 = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(e2, op=dist.ReduceOp.MAX)
+        images_per_s = B * world / float(e2.item())
+        assert logits.shape == (B, 128, 8 * L, 8 * L)
+        del logits
+
+    # ---- roofline of the dominant kernel family (igemm: conv3x3 / conv1x1 / Linear on MFMA) ----
+    roofline = None
+    fam = {}
+    if rank == 0 and args.profile_steps > 0:
+        lib = _lib.lib()
+        lib.ldmseg_profile_reset()
+        lib.ldmseg_profile_enable(1)
+        run_steps(args.profile_steps)
+        torch.cuda.synchronize(dev)
+        lib.ldmseg_profile_enable(0)
+        names = ["igemm", "attention", "groupnorm", "layernorm", "other"]
+        for i, nme in enumerate(names):
+            n_, ms, fl, by = C.c_int64(), C.c_double(), C.c_double(), C.c_double()
+            _lib.check(lib.ldmseg_profile_read(i, C.byref(n_), C.byref(ms), C.byref(fl), C.byref(by)))
+            fam[nme] = {"launches": n_.value, "ms": ms.value, "flops": fl.value, "bytes": by.value}
+        lib.ldmseg_profile_reset()
+        ig = fam["igemm"]
+        peak = PEAK_BF16 if args.dtype == "bf16" else PEAK_F32
+        ach = ig["flops"] / (ig["ms"] * 1e-3) if ig["ms"] > 0 else 0.0
+        roofline = {"bound": "mfma", "kernel": "igemm_kernel (conv3x3/conv1x1/Linear)", "achieved": ach / 1e12,
+                    "peak": peak / 1e12, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                    "launches": ig["launches"], "avg_launch_us": 1e3 * ig["ms"] / max(1, ig["launches"]),
+                    "alg_flops_per_launch": ig["flops"] / max(1, ig["launches"]),
+                    "families_ms_per_step": {k: v["ms"] / args.profile_steps for k, v in fam.items()},
+                    "attention_tflops": (fam["attention"]["flops"] / (fam["attention"]["ms"] * 1e-3) / 1e12)
+                    if fam["attention"]["ms"] > 0 else None}
+    if world > 1:
+        dist.barrier()
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        del unet, vae
+        cpu = cpu_baseline(usd)
+
+    if rank == 0:
+        n_img_steps = B * world * args.steps
+        value = n_img_steps / elapsed
+        flop_step = FLOP_UNET_L64 * (L / 64.0) ** 2 if L != 64 else FLOP_UNET_L64
+        out = {
+            "metric": "denoising-steps/sec", "value": value, "unit": "image-steps/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
+            "data": "synthetic (random-init SD-1.x UNet + seg-VAE weights, synthetic rgb latents)",
+            "config": {"workload": "512x512 COCO-shaped latents (64x64x4), batch 8 per GPU, DDIM, self-conditioned "
+                                   "12-ch UNet without cross-attention (BASELINE configs[1])",
+                       "batch_per_gpu": B, "global_batch": B * world, "latent": L, "parallelism": f"dp{world}"},
+            "images_per_s_50step_ddim_incl_decode": images_per_s,
+            "whole_step_mfma_frac": (B * flop_step * args.steps / elapsed) / (PEAK_BF16 if args.dtype == "bf16" else PEAK_F32),
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        if cpu:
+            out["gpu_over_cpu"] = value / cpu["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

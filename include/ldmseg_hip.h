@@ -168,6 +168,8 @@ const char* ldmseg_version(void);
 int ldmseg_profile_enable(int enable);
 int ldmseg_profile_read(int family, int64_t* launches, double* total_ms, double* flops, double* bytes);
 int ldmseg_profile_reset(void);
+/* one CSV line per recorded launch (family,label,ms,flops); label carries the launch shape */
+int ldmseg_profile_dump(const char* path);
 
 #ifdef __cplusplus
 }

@@ -49,6 +49,8 @@ inline int bke(int dt) { return dt == DT_BF16 ? 64 : 32; }  // channels per 128-
 // ------------------------------------------------------------------ profiling
 struct ProfFamily {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+  std::vector<std::string> label;
+  std::vector<double> lflops;
   int64_t launches = 0;
   double flops = 0, bytes = 0;
 };
@@ -66,9 +68,12 @@ struct Profiler {
 
 struct ProfScope {
   int f; hipStream_t s; hipEvent_t a{}, b{}; bool on;
-  ProfScope(int family, hipStream_t st, double flops, double bytes, bool dry) : f(family), s(st) {
+  ProfScope(int family, hipStream_t st, double flops, double bytes, bool dry, const std::string& label = "")
+      : f(family), s(st) {
     on = g_prof.on && !dry;
     if (on) {
+      g_prof.fam[f].label.push_back(label);
+      g_prof.fam[f].lflops.push_back(flops);
       a = g_prof.get(); b = g_prof.get();
       (void)hipEventRecord(a, s);
       g_prof.fam[f].launches++;
@@ -249,9 +254,21 @@ struct Exec {
   }
 
   int igemm(IgemmParams& p) {
+    if (p.splits == 1) {
+      const int sp = igemm_plan_splits(p, dt);
+      if (sp > 1) {
+        p.splits = sp;
+        p.partial = (float*)ws->scratch((size_t)sp * p.M * p.N * sizeof(float));
+      }
+    }
     const double flops = 2.0 * p.M * (double)p.n_valid * p.taps * (p.C0 + p.C1);
     const double bytes = ((double)p.M * (p.C0 + p.C1) + (double)p.N * p.taps * (p.C0 + p.C1) + (double)p.M * p.n_valid) * esize(dt);
-    ProfScope ps(0, s, flops, bytes, dry());
+    std::string label;
+    if (g_prof.on && !dry())
+      label = "M=" + std::to_string(p.M) + " N=" + std::to_string(p.n_valid) + " K=" + std::to_string(p.taps * (p.C0 + p.C1)) +
+              " taps=" + std::to_string(p.taps) + " stride=" + std::to_string(p.stride) + " up=" + std::to_string(p.up) +
+              " epi=" + std::to_string(p.epi) + " splits=" + std::to_string(p.splits);
+    ProfScope ps(0, s, flops, bytes, dry(), label);
     if (dry()) return 0;
     return launch_igemm(p, dt, s);
   }
@@ -292,7 +309,7 @@ struct Exec {
     g.nchunk = gn_nchunk(B, g.HW);
     g.partial = (float*)ws->scratch((size_t)B * g.nchunk * 32 * 2 * sizeof(float));
     const double bytes = 3.0 * B * g.HW * ctot * esize(dt);
-    ProfScope ps(2, s, 0, bytes, dry());
+    ProfScope ps(2, s, 0, bytes, dry(), "HW=" + std::to_string(g.HW) + " C=" + std::to_string(ctot));
     if (dry()) return 0;
     return launch_groupnorm(g, dt, s);
   }
@@ -532,7 +549,8 @@ int run_transformer(Exec& ex, const TransformerW& t, const Act& x, Act* out) {
   att = ex.new_act(C, x.H, x.W, false);
   {
     const double d = C / 8.0;
-    ProfScope ps(1, ex.s, 4.0 * ex.B * 8 * (double)N * N * d, 4.0 * M * C * esize(ex.dt), ex.dry());
+    ProfScope ps(1, ex.s, 4.0 * ex.B * 8 * (double)N * N * d, 4.0 * M * C * esize(ex.dt), ex.dry(),
+                 "N=" + std::to_string(N) + " C=" + std::to_string(C));
     if (!ex.dry()) TRY(launch_attention(qkv.p, att.p, ex.B, N, C, 8, ex.dt, ex.s));
   }
   // h = to_out(att) + h  (in place on h)
@@ -1044,6 +1062,8 @@ int ldmseg_profile_reset(void) {
   for (auto& f : g_prof.fam) {
     for (auto& e : f.ev) { g_prof.pool.push_back(e.first); g_prof.pool.push_back(e.second); }
     f.ev.clear();
+    f.label.clear();
+    f.lflops.clear();
     f.launches = 0;
     f.flops = f.bytes = 0;
   }
@@ -1064,6 +1084,26 @@ int ldmseg_profile_read(int family, int64_t* launches, double* total_ms, double*
   if (total_ms) *total_ms = ms;
   if (flops) *flops = f.flops;
   if (bytes) *bytes = f.bytes;
+  return 0;
+}
+
+// one CSV line per recorded launch: family,label,ms,flops
+int ldmseg_profile_dump(const char* path) {
+  g_err.clear();
+  FILE* fp = std::fopen(path, "w");
+  if (!fp) return fail(LDMSEG_E_ARG, "cannot open profile dump file");
+  std::fprintf(fp, "family,label,ms,flops\n");
+  for (int fi = 0; fi < 5; ++fi) {
+    ProfFamily& f = g_prof.fam[fi];
+    for (size_t i = 0; i < f.ev.size(); ++i) {
+      (void)hipEventSynchronize(f.ev[i].second);
+      float t = 0;
+      (void)hipEventElapsedTime(&t, f.ev[i].first, f.ev[i].second);
+      std::fprintf(fp, "%d,%s,%.6f,%.0f\n", fi, i < f.label.size() ? f.label[i].c_str() : "", t,
+                   i < f.lflops.size() ? f.lflops[i] : 0.0);
+    }
+  }
+  std::fclose(fp);
   return 0;
 }
 

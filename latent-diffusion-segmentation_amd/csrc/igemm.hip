@@ -18,8 +18,9 @@
 //    8-/16-byte stores along the NHWC channel axis and in-lane GEGLU.
 //  * LDS tiles are [rows][128 B] with the 16-B chunk index XOR (row & 7):
 //    conflict-free for ds_read_b128 over the 16-lane groups of gfx950.
-//  * double-buffered LDS, register-staged global loads issued before the MFMA
-//    block of the current tile, one barrier per K tile, 2 workgroups per CU.
+//  * double-buffered LDS filled by LDS-DMA (global_load_lds_dwordx4, no VGPR round trip and no
+//    ds_write pass); the DMA of tile t+1 is issued before the MFMA block of tile t; one barrier
+//    per K tile; 2 workgroups per CU.  Out-of-image taps read a 16-B page of zeros.
 //  * workgroup id -> (m tile, n tile) is remapped so that each XCD (own L2)
 //    owns a contiguous range of tiles.
 #include "common.h"
@@ -32,6 +33,27 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kRowBytes = 128;
 
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// LDS-DMA: 64 lanes x 16 B from per-lane global addresses into LDS at (wave-uniform) lds_dst +
+// lane*16.  Issued through inline asm so that hipcc does not track it: with the builtin the
+// compiler waits vmcnt(0) before the next ds_read (it cannot prove the DMA target and the tile
+// being read are different stages), which serialises DMA and MFMA.  The caller owns the wait:
+// s_waitcnt vmcnt(0) + barrier before any wave reads the stage.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
+
 struct RowInfo {
   int pix_base;  // b * Hi * Wi
   int iy0, ix0;  // top-left input coordinate (logical, before upsample shift)
@@ -43,9 +65,6 @@ __global__ __launch_bounds__(kThreads) void igemm_kernel(const IgemmParams p) {
   constexpr int BKE = kRowBytes / (int)sizeof(T);  // K elements per tile
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
   constexpr int MF = WTM / 16, NF = WTN / 16;
-  constexpr int AI = BM * 8 / kThreads;  // 16-B chunks of X per thread per tile
-  constexpr int WI = BN * 8 / kThreads;
-  static_assert(BM * 8 % kThreads == 0 && BN * 8 % kThreads == 0, "tile/loader mismatch");
   constexpr int kStageBytes = (BM + BN) * kRowBytes;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -81,14 +100,19 @@ __global__ __launch_bounds__(kThreads) void igemm_kernel(const IgemmParams p) {
   const int pad = (p.taps == 9) ? 1 : 0;
   const int HWo = p.Ho * p.Wo;
 
-  // ---- per-thread gather rows ----
-  const int ld_j = tid & 7;                 // logical 16-B chunk within the 128-B K tile row
-  const int ld_r = tid >> 3;                // row within a 32-row pass
-  const int ld_sw = (ld_j ^ (ld_r & 7)) * 16;
-  RowInfo ri[AI];
+  // ---- direct-to-LDS staging (global_load_lds_dwordx4): one wave instruction fills one 8-row
+  // group (1 KiB, lane l -> row l>>3, physical chunk l&7).  The XOR swizzle therefore lives on the
+  // SOURCE side: the lane fetches logical chunk (l&7)^(row&7).  Rows 0..BM-1 of a stage are X,
+  // rows BM.. are W; group g of instruction i belongs to wave (g & 3).
+  constexpr int XG = BM / 32;                  // X groups per wave per tile
+  constexpr int WG = BN / 32;                  // W groups per wave per tile
+  static_assert(BM % 32 == 0 && BN % 32 == 0, "tile rows must be a multiple of 32");
+  const int ld_r = lane >> 3;                  // row within the 8-row group (== row & 7)
+  const int ld_j = (lane & 7) ^ ld_r;          // logical 16-B chunk this lane fetches
+  RowInfo ri[XG];
 #pragma unroll
-  for (int i = 0; i < AI; ++i) {
-    const int m = m0 + i * 32 + ld_r;
+  for (int i = 0; i < XG; ++i) {
+    const int m = m0 + (i * 4 + wave) * 8 + ld_r;
     if (m < p.M) {
       const int b = m / HWo, rem = m - b * HWo;
       const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
@@ -101,10 +125,13 @@ __global__ __launch_bounds__(kThreads) void igemm_kernel(const IgemmParams p) {
       ri[i].ix0 = 0;
     }
   }
-  const unsigned char* wbase = (const unsigned char*)p.W + ((size_t)(n0 + ld_r) * K) * sizeof(T) + ld_j * 16;
+  const unsigned char* wbase =
+      (const unsigned char*)p.W + ((size_t)(n0 + wave * 8 + ld_r) * K) * sizeof(T) + ld_j * 16;
   const size_t wrow_stride32 = (size_t)32 * K * sizeof(T);
-
-  uint4 xa[AI], wa[WI];
+  const unsigned char* zpage = (const unsigned char*)p.zeros;
+  // wave-uniform LDS byte address of this wave's first group in stage 0
+  const unsigned lds_wave = __builtin_amdgcn_readfirstlane(
+      (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)smem) + (unsigned)wave * 1024u);
 
   // tap / channel cursor of the tile being fetched
   int f_tap = 0, f_cc = 0;
@@ -115,34 +142,29 @@ __global__ __launch_bounds__(kThreads) void igemm_kernel(const IgemmParams p) {
     f_cc = (kt - f_tap * tiles_per_tap) * BKE;
   }
 
-  auto fetch = [&](int kt) {
+  auto fetch = [&](int kt, int stage) {
     const int ky = (p.taps == 9) ? f_tap / 3 : 0;
     const int kx = (p.taps == 9) ? f_tap - ky * 3 : 0;
     const unsigned char* sbase;
     int cs, coff;
     if (f_cc < p.C0) { sbase = (const unsigned char*)p.src0; cs = p.C0; coff = f_cc; }
     else { sbase = (const unsigned char*)p.src1; cs = p.C1; coff = f_cc - p.C0; }
+    const unsigned dst = lds_wave + (unsigned)stage * (unsigned)kStageBytes;
 #pragma unroll
-    for (int i = 0; i < AI; ++i) {
+    for (int i = 0; i < XG; ++i) {
       const int uy = ri[i].iy0 + ky, ux = ri[i].ix0 + kx;
       const bool inb = (uy >= 0) & (uy < Hlog) & (ux >= 0) & (ux < Wlog);
       const int iy = p.up ? (uy >> 1) : uy, ix = p.up ? (ux >> 1) : ux;
       const size_t off = ((size_t)(ri[i].pix_base + iy * p.Wi + ix) * cs + coff) * sizeof(T) + ld_j * 16;
-      xa[i] = inb ? *(const uint4*)(sbase + off) : make_uint4(0, 0, 0, 0);
+      const unsigned char* src = inb ? sbase + off : zpage;
+      glds16(src, dst + i * 4096);
     }
     const unsigned char* wp = wbase + (size_t)kt * kRowBytes;
+    const unsigned wdst = dst + BM * kRowBytes;
 #pragma unroll
-    for (int i = 0; i < WI; ++i) wa[i] = *(const uint4*)(wp + i * wrow_stride32);
+    for (int i = 0; i < WG; ++i) glds16(wp + i * wrow_stride32, wdst + i * 4096);
     f_cc += BKE;
     if (f_cc == Ctot) { f_cc = 0; ++f_tap; }
-  };
-  auto stash = [&](int stage) {
-    unsigned char* xs = smem + stage * kStageBytes;
-    unsigned char* ws = xs + BM * kRowBytes;
-#pragma unroll
-    for (int i = 0; i < AI; ++i) *(uint4*)(xs + (i * 32 + ld_r) * kRowBytes + ld_sw) = xa[i];
-#pragma unroll
-    for (int i = 0; i < WI; ++i) *(uint4*)(ws + (i * 32 + ld_r) * kRowBytes + ld_sw) = wa[i];
   };
 
   f32x4 acc[NF][MF];
@@ -156,16 +178,13 @@ __global__ __launch_bounds__(kThreads) void igemm_kernel(const IgemmParams p) {
   const int fr_c0 = (((lane >> 4)) ^ (lane & 7)) * 16;
   const int fr_c1 = (((lane >> 4) + 4) ^ (lane & 7)) * 16;
 
-  if (kt_begin < kt_end) {
-    fetch(kt_begin);
-    stash(0);
-  }
+  if (kt_begin < kt_end) fetch(kt_begin, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   for (int kt = kt_begin; kt < kt_end; ++kt) {
     const int cur = (kt - kt_begin) & 1;
-    const bool more = (kt + 1 < kt_end);
-    if (more) fetch(kt + 1);
+    if (kt + 1 < kt_end) fetch(kt + 1, cur ^ 1);   // DMA of the next tile flies under this tile's MFMAs
     const unsigned char* xs = smem + cur * kStageBytes + (wm * WTM) * kRowBytes + fr_row;
     const unsigned char* ws = smem + cur * kStageBytes + (BM + wn * WTN) * kRowBytes + fr_row;
 #pragma unroll
@@ -181,8 +200,8 @@ __global__ __launch_bounds__(kThreads) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
         for (int b = 0; b < MF; ++b) mma_kgroup<T>(wf[a], xf[b], acc[a][b]);
     }
-    if (more) stash(cur ^ 1);
-    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of tile kt+1 have landed
+    __syncthreads();                                    // ... and everybody's; stage `cur` is free again
   }
 
   // ---- epilogue: lane holds n = nb + 4*(lane>>4) + r (r=0..3) of m = mb + (lane&15) ----
@@ -306,8 +325,20 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const IgemmParams p)
   }
 }
 
+const void* zero_page() {
+  static void* z = nullptr;
+  if (!z) {
+    if (hipMalloc(&z, 256) != hipSuccess) return nullptr;
+    (void)hipMemset(z, 0, 256);
+  }
+  return z;
+}
+
 template <typename T, int BM, int BN, int WM, int WN>
-int run(const IgemmParams& p, hipStream_t s) {
+int run(const IgemmParams& pin, hipStream_t s) {
+  IgemmParams p = pin;
+  p.zeros = zero_page();
+  if (!p.zeros) return -3;
   const int mt = (p.M + BM - 1) / BM, nt = p.N / BN;
   const size_t lds = 2 * (size_t)(BM + BN) * kRowBytes;
   auto kern = igemm_kernel<T, BM, BN, WM, WN>;
@@ -348,6 +379,23 @@ int igemm_pick_bn(int n_real, int epi) {
   if (n_real >= 128) return 128;
   if (n_real > 32) return 64;
   return 32;
+}
+
+// Split-K plan for grids that would leave most of the 256 CUs idle (the 8x8 / 16x16 feature maps):
+// returns the number of K slices (1 = no split).  Mirrors dispatch()'s tile choice.
+int igemm_plan_splits(const IgemmParams& p, int dtype) {
+  if (p.epi != EPI_STORE) return 1;
+  const int bke = dtype == DT_BF16 ? 64 : 32;
+  const int bn = p.N % 160 == 0 ? 160 : (p.N % 128 == 0 ? 128 : (p.N % 64 == 0 ? 64 : 32));
+  const long tiles128 = (long)((p.M + 127) / 128) * (p.N / bn);
+  const int bm = (bn >= 128 && tiles128 < 200) ? 64 : 128;
+  const long blocks = (long)((p.M + bm - 1) / bm) * (p.N / bn);
+  const int nk = p.taps * (p.C0 + p.C1) / bke;
+  if (blocks >= 200 || nk < 24) return 1;
+  int splits = (int)((400 + blocks - 1) / blocks);
+  if (splits > nk / 12) splits = nk / 12;
+  if (splits > 16) splits = 16;
+  return splits < 2 ? 1 : splits;
 }
 
 size_t igemm_partial_bytes(const IgemmParams& p) {

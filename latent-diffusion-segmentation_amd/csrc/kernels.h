@@ -42,11 +42,13 @@ struct IgemmParams {
   // igemm_splitk_finish applies the epilogue.
   int splits = 1;
   float* partial = nullptr;
+  const void* zeros = nullptr;   // >= 16 B of zeros (set by the launcher)
 };
 
 // returns 0 or a negative error (bad shape)
 int launch_igemm(const IgemmParams& p, int dtype, hipStream_t s);
 size_t igemm_partial_bytes(const IgemmParams& p);
+int igemm_plan_splits(const IgemmParams& p, int dtype);
 // tile the launcher would pick (for weight padding): N tile size for a given N.
 int igemm_pick_bn(int n_real, int epi);
 
