@@ -11,6 +11,8 @@
 // output accumulator O^T is rescaled by a per-lane scalar.  The K-tile rows are
 // read through a fixed permutation so that the 8 bf16 probabilities a lane packs
 // are 8 consecutive keys of the V^T row it multiplies.
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -34,14 +36,37 @@ template <typename T, int D> struct AttnCfg {
   static constexpr int VT_BYTES = DF * 16 * VROW;
 };
 
+// cross-lane reductions over the 4 lanes (l, l^16, l^32, l^48) that share a query row, on the VALU
+// (v_permlane16_swap / v_permlane32_swap) instead of LDS round trips (ds_bpermute)
+__device__ __forceinline__ void swap16(float x, float& a, float& b) {
+  const unsigned u = f32_bits(x);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const unsigned r0 = r[0], r1 = r[1];
+  a = bits_f32(r0);
+  b = bits_f32(r1);
+}
+__device__ __forceinline__ void swap32(float x, float& a, float& b) {
+  const unsigned u = f32_bits(x);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  const unsigned r0 = r[0], r1 = r[1];
+  a = bits_f32(r0);
+  b = bits_f32(r1);
+}
+__device__ __forceinline__ float xor16_max(float x) { float a, b; swap16(x, a, b); return fmaxf(a, b); }
+__device__ __forceinline__ float xor32_max(float x) { float a, b; swap32(x, a, b); return fmaxf(a, b); }
+__device__ __forceinline__ float xor16_sum(float x) { float a, b; swap16(x, a, b); return a + b; }
+__device__ __forceinline__ float xor32_sum(float x) { float a, b; swap32(x, a, b); return a + b; }
+
 template <typename T, int D, int QF>
 __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qkv, T* __restrict__ out,
                                                         int N, int C, int heads, float scale_log2e) {
   using Cfg = AttnCfg<T, D>;
   constexpr int PC = Chunk<T>::N;
+  constexpr int NCH = BKV * Cfg::DCH;          // real 16-B chunks of one K (or V) tile
+  constexpr int KIT = (NCH + 255) / 256;       // chunks per thread per tile
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* Ks = smem;
-  unsigned char* Vt = smem + Cfg::KS_BYTES;
+  constexpr int STAGE = Cfg::KS_BYTES + Cfg::VT_BYTES;
+  constexpr int NST = (2 * STAGE <= 144 * 1024) ? 2 : 1;   // two stages (one barrier per key tile) when they fit
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane & 15, lg = lane >> 4;
@@ -59,11 +84,52 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
   const int h = bh % heads, b = bh / heads;
   const size_t ld = (size_t)3 * C;
   const T* qbase = qkv + (size_t)b * N * ld + (size_t)h * D;
-  const T* kbase = qbase + C;
-  const T* vbase = qbase + 2 * C;
+  const unsigned char* kbase = (const unsigned char*)(qbase + C);
+  const unsigned char* vbase = (const unsigned char*)(qbase + 2 * C);
+  const size_t ldb = ld * sizeof(T);
 
-  // zero V^T once (rows d >= D and the pad stay zero for the whole kernel)
-  for (int i = tid * 16; i < Cfg::VT_BYTES; i += 256 * 16) *(uint4*)(Vt + i) = make_uint4(0, 0, 0, 0);
+  // K/V tile staging: global -> registers (issued before the MFMA block of the previous tile, so
+  // the L2/HBM latency hides under it) -> LDS after that tile's last LDS read.
+  // K chunk i -> (row i / DCH, chunk i % DCH): coalesced 16-B loads, ds_write_b128 rows.
+  // V chunk i -> (row i % 64, chunk i / 64): a wave writes 64 consecutive keys of one d row of
+  // V^T, i.e. consecutive 2-/4-byte LDS addresses - no bank conflicts in the transpose.
+  uint4 kreg[KIT], vreg[KIT];
+  auto prefetch = [&](int t) {
+    const int kv0 = t * BKV;
+#pragma unroll
+    for (int it = 0; it < KIT; ++it) {
+      const int i = tid + it * 256;
+      if (it + 1 < KIT || i < NCH) {
+        // rows past N are clamped to the last key: their scores are masked to -inf below, so the
+        // (finite) duplicate K/V data never contributes
+        const int krow = i / Cfg::DCH, kch = i - krow * Cfg::DCH;
+        kreg[it] = *(const uint4*)(kbase + (size_t)min(kv0 + krow, N - 1) * ldb + kch * 16);
+        const int vrow = i & (BKV - 1), vch = i / BKV;
+        vreg[it] = *(const uint4*)(vbase + (size_t)min(kv0 + vrow, N - 1) * ldb + vch * 16);
+      }
+    }
+  };
+  auto commit = [&](int stage) {
+    unsigned char* Ks = smem + stage * STAGE;
+    unsigned char* Vt = Ks + Cfg::KS_BYTES;
+#pragma unroll
+    for (int it = 0; it < KIT; ++it) {
+      const int i = tid + it * 256;
+      if (it + 1 < KIT || i < NCH) {
+        const int krow = i / Cfg::DCH, kch = i - krow * Cfg::DCH;
+        *(uint4*)(Ks + krow * Cfg::KROW + kch * 16) = kreg[it];
+        const int vrow = i & (BKV - 1), vch = i / BKV;
+        union { uint4 u; T e[PC]; } cv;
+        cv.u = vreg[it];
+#pragma unroll
+        for (int k = 0; k < PC; ++k) *(T*)(Vt + (vch * PC + k) * Cfg::VROW + vrow * sizeof(T)) = cv.e[k];
+      }
+    }
+  };
+
+  prefetch(0);
+  // zero the whole LDS once: K pad chunks (d >= D), V^T rows d >= D and row pads stay zero
+  for (int i = tid * 16; i < NST * STAGE; i += 256 * 16) *(uint4*)(smem + i) = make_uint4(0, 0, 0, 0);
 
   // Q fragments (MFMA B operand): lane (q = lq, g = lg) holds chunk kg*4+g of its row
   const int q0 = qb * 64 * QF + wave * 16 * QF;
@@ -76,6 +142,12 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
       const int ch = kg * 4 + lg;
       qf[a][kg] = (q < N && ch < Cfg::DCH) ? *(const uint4*)((const unsigned char*)(qbase + (size_t)q * ld) + ch * 16)
                                             : make_uint4(0, 0, 0, 0);
+      // fold d^-1/2 * log2(e) into Q once, so that the scores come out of the MFMA in exp2 units
+      float qv[PC];
+      Chunk<T>::unpack(qf[a][kg], qv);
+#pragma unroll
+      for (int e = 0; e < PC; ++e) qv[e] *= scale_log2e;
+      qf[a][kg] = Chunk<T>::pack(qv);
     }
   }
 
@@ -90,37 +162,21 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
   }
 
   // K-tile row read by MFMA row i of score fragment f (see header comment)
-  int krow[4];
+  int krow_f[4];
 #pragma unroll
   for (int f = 0; f < 4; ++f) {
-    if constexpr (sizeof(T) == 2) krow[f] = 32 * (f >> 1) + 8 * (lq >> 2) + (lq & 3) + 4 * (f & 1);
-    else krow[f] = 16 * f + lq;
+    if constexpr (sizeof(T) == 2) krow_f[f] = 32 * (f >> 1) + 8 * (lq >> 2) + (lq & 3) + 4 * (f & 1);
+    else krow_f[f] = 16 * f + lq;
   }
 
-  const int ntiles = (N + BKV - 1) / BKV;
-  for (int t = 0; t < ntiles; ++t) {
-    const int kv0 = t * BKV;
-    __syncthreads();
-    // ---- stage K (row-major, zero padded) and V (transposed) ----
-    for (int i = tid; i < BKV * Cfg::KCH; i += 256) {
-      const int row = i / Cfg::KCH, ch = i - row * Cfg::KCH;
-      const int kv = kv0 + row;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (kv < N && ch < Cfg::DCH) v = *(const uint4*)((const unsigned char*)(kbase + (size_t)kv * ld) + ch * 16);
-      *(uint4*)(Ks + row * Cfg::KROW + ch * 16) = v;
-    }
-    for (int i = tid; i < BKV * Cfg::DCH; i += 256) {
-      const int row = i / Cfg::DCH, ch = i - row * Cfg::DCH;
-      const int kv = kv0 + row;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (kv < N) v = *(const uint4*)((const unsigned char*)(vbase + (size_t)kv * ld) + ch * 16);
-      union { uint4 u; T e[PC]; } cv;
-      cv.u = v;
-#pragma unroll
-      for (int k = 0; k < PC; ++k) *(T*)(Vt + (ch * PC + k) * Cfg::VROW + row * sizeof(T)) = cv.e[k];
-    }
-    __syncthreads();
+  __syncthreads();
+  commit(0);
+  __syncthreads();
 
+  auto tile = [&](int kv0, int stage, auto ragged_tag) {
+    constexpr bool RAGGED = decltype(ragged_tag)::value;
+    const unsigned char* Ks = smem + stage * STAGE;
+    const unsigned char* Vt = Ks + Cfg::KS_BYTES;
     // ---- S^T = K Q^T ----
     f32x4 s[QF][4];
 #pragma unroll
@@ -131,14 +187,16 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
     for (int kg = 0; kg < Cfg::KG; ++kg) {
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
-        const uint4 kf = *(const uint4*)(Ks + krow[f] * Cfg::KROW + (kg * 4 + lg) * 16);
+        const uint4 kf = *(const uint4*)(Ks + krow_f[f] * Cfg::KROW + (kg * 4 + lg) * 16);
 #pragma unroll
         for (int a = 0; a < QF; ++a) mma_kgroup<T>(kf, qf[a][kg], s[a][f]);
       }
     }
 
-    // ---- online softmax (lane = one query row, 16 of its 64 scores) ----
-    const bool ragged = (kv0 + BKV > N);
+    // ---- online softmax (lane = one query row, 16 of its 64 scores); scores are already in
+    // exp2 units (scale folded into Q), so each costs one subtract + one raw v_exp_f32 ----
+    float alpha[QF];
+    bool grew = false;
 #pragma unroll
     for (int a = 0; a < QF; ++a) {
       float tmax = -INFINITY;
@@ -146,33 +204,40 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
       for (int f = 0; f < 4; ++f)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float z = s[a][f][r] * scale_log2e;
-          if (ragged) {
+          float z = s[a][f][r];
+          if constexpr (RAGGED) {
             int kv;
             if constexpr (sizeof(T) == 2) kv = kv0 + 32 * (f >> 1) + 8 * lg + r + 4 * (f & 1);
             else kv = kv0 + 16 * f + 4 * lg + r;
             if (kv >= N) z = -INFINITY;
+            s[a][f][r] = z;
           }
-          s[a][f][r] = z;
           tmax = fmaxf(tmax, z);
         }
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 16));
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+      tmax = xor32_max(xor16_max(tmax));
       const float mnew = fmaxf(mrow[a], tmax);   // finite: key kv0 is always valid
-      const float alpha = exp2f(mrow[a] - mnew);
+      grew |= (mnew > mrow[a]);
+      alpha[a] = __builtin_amdgcn_exp2f(mrow[a] - mnew);
       mrow[a] = mnew;
       float ps = 0.f;
 #pragma unroll
       for (int f = 0; f < 4; ++f)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float pv = exp2f(s[a][f][r] - mnew);
+          const float z = s[a][f][r];
+          const float pv = __builtin_amdgcn_exp2f(z - mnew);
           s[a][f][r] = pv;
           ps += pv;
         }
-      lrow[a] = lrow[a] * alpha + ps;
+      lrow[a] = lrow[a] * alpha[a] + ps;
+    }
+    // rescale O only when some row's running max actually grew in this tile (alpha == 1 exactly
+    // otherwise): after the first few tiles this skips the accumulator round trip entirely
+    if (__any(grew)) {
 #pragma unroll
-      for (int d = 0; d < Cfg::DF; ++d) o[a][d] *= alpha;
+      for (int a = 0; a < QF; ++a)
+#pragma unroll
+        for (int d = 0; d < Cfg::DF; ++d) o[a][d] *= alpha[a];
     }
 
     // ---- O^T += V^T P^T ----
@@ -182,9 +247,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
 #pragma unroll
       for (int a = 0; a < QF; ++a) {
         if constexpr (sizeof(T) == 2) {
-          pb[a] = make_uint4(pack_bf16x2(s[a][2 * g][0], s[a][2 * g][1]), pack_bf16x2(s[a][2 * g][2], s[a][2 * g][3]),
-                             pack_bf16x2(s[a][2 * g + 1][0], s[a][2 * g + 1][1]),
-                             pack_bf16x2(s[a][2 * g + 1][2], s[a][2 * g + 1][3]));
+          const float p0 = s[a][2 * g][0], p1 = s[a][2 * g][1], p2 = s[a][2 * g][2], p3 = s[a][2 * g][3];
+          const float p4 = s[a][2 * g + 1][0], p5 = s[a][2 * g + 1][1], p6 = s[a][2 * g + 1][2], p7 = s[a][2 * g + 1][3];
+          pb[a] = make_uint4(pack_bf16x2(p0, p1), pack_bf16x2(p2, p3), pack_bf16x2(p4, p5), pack_bf16x2(p6, p7));
         } else {
           const float p0 = s[a][g][0], p1 = s[a][g][1], p2 = s[a][g][2], p3 = s[a][g][3];
           pb[a] = make_uint4(f32_bits(p0), f32_bits(p1), f32_bits(p2), f32_bits(p3));
@@ -197,14 +262,30 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
         for (int a = 0; a < QF; ++a) mma_kgroup<T>(vf, pb[a], o[a][d]);
       }
     }
+  };
+
+  const int ntiles = (N + BKV - 1) / BKV;
+  const int nfull = N / BKV;                 // tiles without masked keys
+  for (int t = 0; t < ntiles; ++t) {
+    const bool more = t + 1 < ntiles;
+    if (more) prefetch(t + 1);
+    const int st = (NST == 2) ? (t & 1) : 0;
+    if (t < nfull) tile(t * BKV, st, std::false_type{});
+    else tile(t * BKV, st, std::true_type{});
+    if constexpr (NST == 2) {
+      if (more) commit(st ^ 1);   // the other stage was last read before the previous barrier
+      __syncthreads();
+    } else if (more) {
+      __syncthreads();
+      commit(0);
+      __syncthreads();
+    }
   }
 
   // ---- normalise and store: lane (q, g) holds d = df*16 + 4g + r ----
 #pragma unroll
   for (int a = 0; a < QF; ++a) {
-    float l = lrow[a];
-    l += __shfl_xor(l, 16);
-    l += __shfl_xor(l, 32);
+    const float l = xor32_sum(xor16_sum(lrow[a]));
     const float inv = 1.0f / l;
     const int q = q0 + a * 16 + lq;
     if (q >= N) continue;
@@ -214,8 +295,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
       const int dd = d * 16 + 4 * lg;
       if (dd >= D) continue;
       const f32x4 v = o[a][d] * inv;
+      const float v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3];
       if constexpr (sizeof(T) == 2) {
-        *(uint2*)(op + dd) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+        *(uint2*)(op + dd) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
       } else {
         *(f32x4*)(op + dd) = v;
       }
@@ -226,7 +308,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
 template <typename T, int D, int QF>
 int run(const void* qkv, void* out, int B, int N, int C, int heads, hipStream_t s) {
   using Cfg = AttnCfg<T, D>;
-  const size_t lds = Cfg::KS_BYTES + Cfg::VT_BYTES;
+  const size_t stage = (size_t)(Cfg::KS_BYTES + Cfg::VT_BYTES);
+  const size_t lds = (2 * stage <= 144 * 1024 ? 2 : 1) * stage;
   auto kern = attention_kernel<T, D, QF>;
   static bool attr_set = false;
   if (!attr_set) {

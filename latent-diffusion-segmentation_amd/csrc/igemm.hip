@@ -361,8 +361,9 @@ int run(const IgemmParams& pin, hipStream_t s) {
 template <typename T>
 int dispatch(const IgemmParams& p, hipStream_t s) {
   const int bn = (p.epi == EPI_GEGLU) ? 128 : (p.N % 160 == 0 ? 160 : (p.N % 128 == 0 ? 128 : (p.N % 64 == 0 ? 64 : 32)));
-  // under-filled grids: halve the M tile so more CUs get work
-  const bool small = (long)((p.M + 127) / 128) * (p.N / bn) < 200;
+  // fewer than ~1.5 workgroups per CU with 128-row tiles: halve the M tile (2 co-resident
+  // workgroups per CU are what hides the per-K-tile barrier)
+  const bool small = (long)((p.M + 127) / 128) * (p.N / bn) < 400;
   switch (bn) {
     case 160: return small ? run<T, 64, 160, 2, 2>(p, s) : run<T, 128, 160, 2, 2>(p, s);
     case 128: return small ? run<T, 64, 128, 2, 2>(p, s) : run<T, 128, 128, 2, 2>(p, s);
@@ -388,11 +389,11 @@ int igemm_plan_splits(const IgemmParams& p, int dtype) {
   const int bke = dtype == DT_BF16 ? 64 : 32;
   const int bn = p.N % 160 == 0 ? 160 : (p.N % 128 == 0 ? 128 : (p.N % 64 == 0 ? 64 : 32));
   const long tiles128 = (long)((p.M + 127) / 128) * (p.N / bn);
-  const int bm = (bn >= 128 && tiles128 < 200) ? 64 : 128;
+  const int bm = (bn >= 128 && tiles128 < 400) ? 64 : 128;
   const long blocks = (long)((p.M + bm - 1) / bm) * (p.N / bn);
   const int nk = p.taps * (p.C0 + p.C1) / bke;
-  if (blocks >= 200 || nk < 24) return 1;
-  int splits = (int)((400 + blocks - 1) / blocks);
+  if (blocks >= 400 || nk < 24) return 1;
+  int splits = (int)((512 + blocks - 1) / blocks);
   if (splits > nk / 12) splits = nk / 12;
   if (splits > 16) splits = 16;
   return splits < 2 ? 1 : splits;

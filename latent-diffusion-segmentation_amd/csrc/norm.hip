@@ -111,22 +111,43 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GNParams p) {
     s_rstd[g] = (float)(1.0 / sqrt(var + (double)p.eps));
   }
   __syncthreads();
-  const size_t total = (size_t)p.HW * nvec;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int pix = (int)(i / nvec), v = (int)(i - (size_t)pix * nvec);
-    const uint4 raw = load_cat<T>(p, b, pix, v);
-    float f[PC];
-    Chunk<T>::unpack(raw, f);
+  // every thread owns fixed channel vectors, so the per-channel affine (x*a + b with
+  // a = rstd*gamma, b = beta - mean*a) is computed once and the pixel loop is one FMA per element
+  const int VX = nvec < 256 ? nvec : 256;
+  const int TY = 256 / VX;
+  const int tid = threadIdx.x;
+  const int tx = tid % VX, ty = tid / VX;
+  if (ty >= TY) return;
+  const int per = (p.HW + gridDim.x - 1) / gridDim.x;
+  const int p0 = blockIdx.x * per;
+  const int p1 = min(p.HW, p0 + per);
+  for (int v = tx; v < nvec; v += VX) {
     const int c0 = v * PC;
+    float a[PC], bb[PC];
 #pragma unroll
     for (int e = 0; e < PC; ++e) {
       const int c = c0 + e;
       const int g = c / cpg;
-      float y = (f[e] - s_mean[g]) * s_rstd[g] * p.gamma[c] + p.beta[c];
-      if (p.silu) y = silu_f(y);
-      f[e] = y;
+      a[e] = s_rstd[g] * p.gamma[c];
+      bb[e] = p.beta[c] - s_mean[g] * a[e];
     }
-    *(uint4*)((T*)p.out + ((size_t)b * p.HW + pix) * C + c0) = Chunk<T>::pack(f);
+    const T* src;
+    int cs, coff;
+    if (c0 < p.C0) { src = (const T*)p.src0; cs = p.C0; coff = c0; }
+    else { src = (const T*)p.src1; cs = p.C1; coff = c0 - p.C0; }
+    src += (size_t)b * p.HW * cs + coff;
+    T* dst = (T*)p.out + (size_t)b * p.HW * C + c0;
+    for (int pix = p0 + ty; pix < p1; pix += TY) {
+      float f[PC];
+      Chunk<T>::unpack(*(const uint4*)(src + (size_t)pix * cs), f);
+#pragma unroll
+      for (int e = 0; e < PC; ++e) {
+        float y = f[e] * a[e] + bb[e];
+        if (p.silu) y = silu_f(y);
+        f[e] = y;
+      }
+      *(uint4*)(dst + (size_t)pix * C) = Chunk<T>::pack(f);
+    }
   }
 }
 
@@ -192,10 +213,13 @@ int run_gn(const GNParams& p, hipStream_t s) {
   if (C / p.groups < PC) return -2;               // a 16-B vector may span at most two groups
   if (C / PC > 256 * kMaxIter) return -2;
   hipLaunchKernelGGL(gn_partial_kernel<T>, dim3(p.nchunk, p.B), dim3(256), 0, s, p);
-  const size_t total = (size_t)p.HW * (C / PC);
-  int blocks = (int)((total + 255) / 256);
+  // pixel chunks: >= 4 pixels per thread row, ~2048 workgroups in total
+  const int nvec = C / PC;
+  const int ty = 256 / (nvec < 256 ? nvec : 256);
+  int blocks = (p.HW + 4 * ty - 1) / (4 * ty);
   const int cap = max(1, 2048 / p.B);
   if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(blocks, p.B), dim3(256), 0, s, p);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }

@@ -13,7 +13,10 @@ CSRC = os.path.normpath(os.path.join(HERE, "..", "csrc"))
 INCLUDE = os.path.normpath(os.path.join(HERE, "..", "..", "include"))
 LIB_PATH = os.path.join(HERE, "libldmseg_hip.so")
 SOURCES = ["igemm.hip", "norm.hip", "attention.hip", "misc.hip", "sched.hip", "engine.hip", "ops_api.hip"]
-EXTRA_FLAGS = {"sched.hip": ["-ffp-contract=off"]}   # bit-exact scheduler arithmetic
+EXTRA_FLAGS = {
+    "sched.hip": ["-ffp-contract=off"],                       # bit-exact scheduler arithmetic
+    "attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],    # scores feed VALU softmax: keep MFMA results in VGPRs
+}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 
 
