@@ -42,15 +42,22 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // being read are different stages), which serialises DMA and MFMA.  The caller owns the wait:
 // s_waitcnt vmcnt(0) + barrier before any wave reads the stage.
 __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
-  unsigned keep;
   asm volatile(
-      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %1\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %0, off"
+      :
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
+// same, address = wave-uniform 64-bit base (SGPR pair) + per-lane 32-bit offset: no VALU per tile
+__device__ __forceinline__ void glds16_sbase(unsigned voff, const void* sbase, unsigned lds_dst) {
+  asm volatile(
       "s_mov_b32 m0, %2\n\t"
       "s_nop 0\n\t"
-      "global_load_lds_dwordx4 %1, off\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(gsrc), "s"(lds_dst)
+      "global_load_lds_dwordx4 %0, %1"
+      :
+      : "v"(voff), "s"(sbase), "s"(lds_dst)
       : "memory");
 }
 
@@ -125,9 +132,12 @@ __global__ __launch_bounds__(kThreads) void igemm_kernel(const IgemmParams p) {
       ri[i].ix0 = 0;
     }
   }
-  const unsigned char* wbase =
-      (const unsigned char*)p.W + ((size_t)(n0 + wave * 8 + ld_r) * K) * sizeof(T) + ld_j * 16;
-  const size_t wrow_stride32 = (size_t)32 * K * sizeof(T);
+  // W rows: wave-uniform base (advances 128 B per K tile) + per-lane 32-bit offsets
+  const unsigned char* wtile0 = (const unsigned char*)p.W + (size_t)n0 * K * sizeof(T);
+  unsigned woff[WG];
+#pragma unroll
+  for (int i = 0; i < WG; ++i)
+    woff[i] = (unsigned)(((size_t)(i * 32 + wave * 8 + ld_r) * K) * sizeof(T)) + (unsigned)ld_j * 16u;
   const unsigned char* zpage = (const unsigned char*)p.zeros;
   // wave-uniform LDS byte address of this wave's first group in stage 0
   const unsigned lds_wave = __builtin_amdgcn_readfirstlane(
@@ -142,29 +152,45 @@ __global__ __launch_bounds__(kThreads) void igemm_kernel(const IgemmParams p) {
     f_cc = (kt - f_tap * tiles_per_tap) * BKE;
   }
 
-  auto fetch = [&](int kt, int stage) {
+  // A "segment" is a run of K tiles inside one (tap, source tensor): there the gather address of a
+  // row only advances by 128 B per tile.  Row pointers are set up once per segment; rows whose tap
+  // falls outside the image sit on the zero page with stride 0.
+  const unsigned char* rowptr[XG];
+  unsigned rowinc[XG];
+  bool need_setup = true;
+  auto seg_setup = [&]() {
     const int ky = (p.taps == 9) ? f_tap / 3 : 0;
     const int kx = (p.taps == 9) ? f_tap - ky * 3 : 0;
     const unsigned char* sbase;
     int cs, coff;
     if (f_cc < p.C0) { sbase = (const unsigned char*)p.src0; cs = p.C0; coff = f_cc; }
     else { sbase = (const unsigned char*)p.src1; cs = p.C1; coff = f_cc - p.C0; }
-    const unsigned dst = lds_wave + (unsigned)stage * (unsigned)kStageBytes;
 #pragma unroll
     for (int i = 0; i < XG; ++i) {
       const int uy = ri[i].iy0 + ky, ux = ri[i].ix0 + kx;
       const bool inb = (uy >= 0) & (uy < Hlog) & (ux >= 0) & (ux < Wlog);
       const int iy = p.up ? (uy >> 1) : uy, ix = p.up ? (ux >> 1) : ux;
       const size_t off = ((size_t)(ri[i].pix_base + iy * p.Wi + ix) * cs + coff) * sizeof(T) + ld_j * 16;
-      const unsigned char* src = inb ? sbase + off : zpage;
-      glds16(src, dst + i * 4096);
+      rowptr[i] = inb ? sbase + off : zpage;
+      rowinc[i] = inb ? (unsigned)kRowBytes : 0u;
     }
-    const unsigned char* wp = wbase + (size_t)kt * kRowBytes;
+  };
+
+  auto fetch = [&](int kt, int stage) {
+    if (need_setup) seg_setup();
+    const unsigned dst = lds_wave + (unsigned)stage * (unsigned)kStageBytes;
+#pragma unroll
+    for (int i = 0; i < XG; ++i) {
+      glds16(rowptr[i], dst + i * 4096);
+      rowptr[i] += rowinc[i];
+    }
+    const unsigned char* wt = wtile0 + (size_t)kt * kRowBytes;
     const unsigned wdst = dst + BM * kRowBytes;
 #pragma unroll
-    for (int i = 0; i < WG; ++i) glds16(wp + i * wrow_stride32, wdst + i * 4096);
+    for (int i = 0; i < WG; ++i) glds16_sbase(woff[i], wt, wdst + i * 4096);
     f_cc += BKE;
     if (f_cc == Ctot) { f_cc = 0; ++f_tap; }
+    need_setup = (f_cc == 0) | (f_cc == p.C0);
   };
 
   f32x4 acc[NF][MF];
