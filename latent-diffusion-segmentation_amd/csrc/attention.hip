@@ -36,27 +36,8 @@ template <typename T, int D> struct AttnCfg {
   static constexpr int VT_BYTES = DF * 16 * VROW;
 };
 
-// cross-lane reductions over the 4 lanes (l, l^16, l^32, l^48) that share a query row, on the VALU
-// (v_permlane16_swap / v_permlane32_swap) instead of LDS round trips (ds_bpermute)
-__device__ __forceinline__ void swap16(float x, float& a, float& b) {
-  const unsigned u = f32_bits(x);
-  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-  const unsigned r0 = r[0], r1 = r[1];
-  a = bits_f32(r0);
-  b = bits_f32(r1);
-}
-__device__ __forceinline__ void swap32(float x, float& a, float& b) {
-  const unsigned u = f32_bits(x);
-  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-  const unsigned r0 = r[0], r1 = r[1];
-  a = bits_f32(r0);
-  b = bits_f32(r1);
-}
-__device__ __forceinline__ float xor16_max(float x) { float a, b; swap16(x, a, b); return fmaxf(a, b); }
-__device__ __forceinline__ float xor32_max(float x) { float a, b; swap32(x, a, b); return fmaxf(a, b); }
-__device__ __forceinline__ float xor16_sum(float x) { float a, b; swap16(x, a, b); return a + b; }
-__device__ __forceinline__ float xor32_sum(float x) { float a, b; swap32(x, a, b); return a + b; }
-
+// row statistics reduce over the 4 lanes (l, l^16, l^32, l^48) that share a query row with
+// v_permlane16_swap / v_permlane32_swap (common.h) instead of LDS round trips (ds_bpermute)
 template <typename T, int D, int QF>
 __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qkv, T* __restrict__ out,
                                                         int N, int C, int heads, float scale_log2e) {

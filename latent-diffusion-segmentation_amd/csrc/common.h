@@ -74,6 +74,40 @@ template <> struct Chunk<bf16_t> {
   }
 };
 
+// ---- cross-lane reductions on the VALU (DPP + v_permlane{16,32}_swap), no LDS round trips ----
+__device__ __forceinline__ void swap16(float x, float& a, float& b) {
+  const unsigned u = f32_bits(x);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const unsigned r0 = r[0], r1 = r[1];
+  a = bits_f32(r0);
+  b = bits_f32(r1);
+}
+__device__ __forceinline__ void swap32(float x, float& a, float& b) {
+  const unsigned u = f32_bits(x);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  const unsigned r0 = r[0], r1 = r[1];
+  a = bits_f32(r0);
+  b = bits_f32(r1);
+}
+__device__ __forceinline__ float xor16_max(float x) { float a, b; swap16(x, a, b); return fmaxf(a, b); }
+__device__ __forceinline__ float xor32_max(float x) { float a, b; swap32(x, a, b); return fmaxf(a, b); }
+__device__ __forceinline__ float xor16_sum(float x) { float a, b; swap16(x, a, b); return a + b; }
+__device__ __forceinline__ float xor32_sum(float x) { float a, b; swap32(x, a, b); return a + b; }
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float x) {
+  return bits_f32((unsigned)__builtin_amdgcn_update_dpp(0, (int)f32_bits(x), CTRL, 0xf, 0xf, true));
+}
+// sum over the 16 lanes of a DPP row: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_f<0xB1>(v);
+  v += dpp_f<0x4E>(v);
+  v += dpp_f<0x141>(v);
+  v += dpp_f<0x140>(v);
+  return v;
+}
+// all-lanes sum of a wave64, result in every lane
+__device__ __forceinline__ float wave64_sum(float v) { return xor32_sum(xor16_sum(row16_sum(v))); }
+
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 // erf-GELU (torch.nn.functional.gelu default).  erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7,
 // far inside the 1e-3 parity budget): one v_rcp + one v_exp + a 5-term Horner instead of libm's erff.

@@ -595,6 +595,10 @@ int unet_forward_impl(ldmseg_unet* u, const float* a, int Ca, const float* b, in
   const int dt = u->dt;
 
   // --- time embedding: sinusoid -> MLP -> every resnet's time_emb_proj(SiLU(emb)) ---
+  // a scalar timestep (timestep.expand(B), unet.py:302-303) gives every image the same embedding:
+  // run the MLP for one row and broadcast it (row stride 0) instead of B identical rows
+  const bool per_sample_t = (t_dev != nullptr && t_count > 1);
+  const int TB = per_sample_t ? B : 1;
   float* sinus = (float*)ws->persist((size_t)B * 320 * sizeof(float));
   float* e1 = (float*)ws->persist((size_t)B * kTimeDim * sizeof(float));
   float* emb = (float*)ws->persist((size_t)B * kTimeDim * sizeof(float));
@@ -602,13 +606,13 @@ int unet_forward_impl(ldmseg_unet* u, const float* a, int Ca, const float* b, in
   {
     ProfScope ps(4, s, 0, 0, dry);
     if (!dry) {
-      TRY(launch_time_embed(t_dev, t_count, t_host, B, sinus, s));
-      TRY(launch_small_linear(sinus, u->te1_w, u->te1_b, e1, B, 320, kTimeDim, 0, 1, s));
-      TRY(launch_small_linear(e1, u->te2_w, u->te2_b, emb, B, kTimeDim, kTimeDim, 0, 0, s));
-      TRY(launch_small_linear(emb, u->tproj_w, u->tproj_b, temb, B, kTimeDim, u->temb_total, 1, 0, s));
+      TRY(launch_time_embed(t_dev, t_count, t_host, TB, sinus, s));
+      TRY(launch_small_linear(sinus, u->te1_w, u->te1_b, e1, TB, 320, kTimeDim, 0, 1, s));
+      TRY(launch_small_linear(e1, u->te2_w, u->te2_b, emb, TB, kTimeDim, kTimeDim, 0, 0, s));
+      TRY(launch_small_linear(emb, u->tproj_w, u->tproj_b, temb, TB, kTimeDim, u->temb_total, 1, 0, s));
     }
   }
-  const int tstride = u->temb_total;
+  const int tstride = per_sample_t ? u->temb_total : 0;
 
   // --- conv_in on the channel-concatenated fp32 NCHW input ---
   Act xin = ex.new_act(bke(dt), L, L, true);

@@ -95,20 +95,31 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GNParams p) {
   const int nvec = C / PC;
   const int b = blockIdx.y;
   __shared__ float s_mean[64], s_rstd[64];
-  if ((int)threadIdx.x < p.groups) {
-    const int g = threadIdx.x;
+  {
+    // combine the per-chunk partials: 8 lanes per group (fixed chunk order per lane, fixed
+    // shuffle tree -> deterministic), fp64 for the final mean/variance
+    const int g = threadIdx.x >> 3, sub = threadIdx.x & 7;
     double s = 0.0, q = 0.0;
-    for (int ch = 0; ch < p.nchunk; ++ch) {
-      const float* pp = p.partial + (((size_t)b * p.nchunk + ch) * p.groups + g) * 2;
-      s += (double)pp[0];
-      q += (double)pp[1];
+    if (g < p.groups) {
+      for (int ch = sub; ch < p.nchunk; ch += 8) {
+        const float2 pp = *(const float2*)(p.partial + (((size_t)b * p.nchunk + ch) * p.groups + g) * 2);
+        s += (double)pp.x;
+        q += (double)pp.y;
+      }
     }
-    const double n = (double)p.HW * cpg;
-    const double mean = s / n;
-    double var = q / n - mean * mean;
-    if (var < 0.0) var = 0.0;
-    s_mean[g] = (float)mean;
-    s_rstd[g] = (float)(1.0 / sqrt(var + (double)p.eps));
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) {
+      s += __shfl_xor(s, o);
+      q += __shfl_xor(q, o);
+    }
+    if (g < p.groups && sub == 0) {
+      const double n = (double)p.HW * cpg;
+      const double mean = s / n;
+      double var = q / n - mean * mean;
+      if (var < 0.0) var = 0.0;
+      s_mean[g] = (float)mean;
+      s_rstd[g] = (float)(1.0 / sqrt(var + (double)p.eps));
+    }
   }
   __syncthreads();
   // every thread owns fixed channel vectors, so the per-channel affine (x*a + b with
@@ -151,56 +162,73 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GNParams p) {
   }
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
+__device__ __forceinline__ float wave_sum(float v) { return wave64_sum(v); }
 
-// one wave per row; C*sizeof(T)/16 <= 64*VPL chunks
-template <typename T, int VPL>
+// Each wave keeps gamma/beta of its channel vectors in registers and walks rows in batches of RPW
+// (all RPW row loads are issued before the first reduction, so several KB per wave are in flight);
+// C*sizeof(T)/16 <= 64*VPL chunks per row.
+template <typename T, int VPL, int RPW>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* x, T* y, const float* gamma, const float* beta,
                                                         int M, int C, float eps, int silu) {
   constexpr int PC = Chunk<T>::N;
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
   const int nvec = C / PC;
-  float f[VPL][PC];
-  float s = 0.f;
+  float g[VPL][PC], bt[VPL][PC];
 #pragma unroll
   for (int k = 0; k < VPL; ++k) {
     const int v = lane + k * 64;
-    if (v < nvec) {
-      const uint4 raw = *(const uint4*)(x + (size_t)row * C + v * PC);
-      Chunk<T>::unpack(raw, f[k]);
 #pragma unroll
-      for (int e = 0; e < PC; ++e) s += f[k][e];
+    for (int e = 0; e < PC; ++e) {
+      g[k][e] = v < nvec ? gamma[v * PC + e] : 0.f;
+      bt[k][e] = v < nvec ? beta[v * PC + e] : 0.f;
     }
   }
-  const float mean = wave_sum(s) / (float)C;
-  float q = 0.f;
+  const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * 4;
+  const float invC = 1.0f / (float)C;
+  for (int row0 = wave_global * RPW; row0 < M; row0 += nwaves * RPW) {
+    uint4 raw[RPW][VPL];
 #pragma unroll
-  for (int k = 0; k < VPL; ++k) {
-    const int v = lane + k * 64;
-    if (v < nvec) {
+    for (int r = 0; r < RPW; ++r)
 #pragma unroll
-      for (int e = 0; e < PC; ++e) { const float d = f[k][e] - mean; q += d * d; }
-    }
-  }
-  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)C + eps);
-#pragma unroll
-  for (int k = 0; k < VPL; ++k) {
-    const int v = lane + k * 64;
-    if (v < nvec) {
-      const int c0 = v * PC;
-#pragma unroll
-      for (int e = 0; e < PC; ++e) {
-        float o = (f[k][e] - mean) * rstd * gamma[c0 + e] + beta[c0 + e];
-        if (silu) o = silu_f(o);
-        f[k][e] = o;
+      for (int k = 0; k < VPL; ++k) {
+        const int v = lane + k * 64;
+        raw[r][k] = (v < nvec && row0 + r < M) ? *(const uint4*)(x + (size_t)(row0 + r) * C + v * PC) : make_uint4(0, 0, 0, 0);
       }
-      *(uint4*)(y + (size_t)row * C + c0) = Chunk<T>::pack(f[k]);
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      if (row0 + r >= M) break;
+      float f[VPL][PC];
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < VPL; ++k) {
+        Chunk<T>::unpack(raw[r][k], f[k]);
+#pragma unroll
+        for (int e = 0; e < PC; ++e) s += f[k][e];      // padding vectors are zero
+      }
+      const float mean = wave_sum(s) * invC;
+      float q = 0.f;
+#pragma unroll
+      for (int k = 0; k < VPL; ++k) {
+        if (lane + k * 64 < nvec) {
+#pragma unroll
+          for (int e = 0; e < PC; ++e) { const float d = f[k][e] - mean; q += d * d; }
+        }
+      }
+      const float rstd = 1.0f / sqrtf(wave_sum(q) * invC + eps);
+#pragma unroll
+      for (int k = 0; k < VPL; ++k) {
+        const int v = lane + k * 64;
+        if (v < nvec) {
+#pragma unroll
+          for (int e = 0; e < PC; ++e) {
+            float o = (f[k][e] - mean) * rstd * g[k][e] + bt[k][e];
+            if (silu) o = silu_f(o);
+            f[k][e] = o;
+          }
+          *(uint4*)(y + (size_t)(row0 + r) * C + v * PC) = Chunk<T>::pack(f[k]);
+        }
+      }
     }
   }
 }
@@ -230,12 +258,17 @@ int run_ln(const void* x, void* y, const float* g, const float* b, int M, int C,
   if (C % PC != 0) return -2;
   const int nvec = C / PC;
   const int vpl = (nvec + 63) / 64;
-  dim3 grid((M + 3) / 4), block(256);
+  dim3 block(256);
+  auto grid_for_rpw = [&](int rpw) {
+    int blocks = (M + 4 * rpw - 1) / (4 * rpw);
+    if (blocks > 2048) blocks = 2048;      // grid-stride over row batches beyond that
+    return dim3(blocks < 1 ? 1 : blocks);
+  };
   switch (vpl) {
-    case 1: hipLaunchKernelGGL((layernorm_kernel<T, 1>), grid, block, 0, s, (const T*)x, (T*)y, g, b, M, C, eps, silu); break;
-    case 2: hipLaunchKernelGGL((layernorm_kernel<T, 2>), grid, block, 0, s, (const T*)x, (T*)y, g, b, M, C, eps, silu); break;
-    case 3: hipLaunchKernelGGL((layernorm_kernel<T, 3>), grid, block, 0, s, (const T*)x, (T*)y, g, b, M, C, eps, silu); break;
-    case 4: case 5: hipLaunchKernelGGL((layernorm_kernel<T, 5>), grid, block, 0, s, (const T*)x, (T*)y, g, b, M, C, eps, silu); break;
+    case 1: hipLaunchKernelGGL((layernorm_kernel<T, 1, 4>), grid_for_rpw(4), block, 0, s, (const T*)x, (T*)y, g, b, M, C, eps, silu); break;
+    case 2: hipLaunchKernelGGL((layernorm_kernel<T, 2, 4>), grid_for_rpw(4), block, 0, s, (const T*)x, (T*)y, g, b, M, C, eps, silu); break;
+    case 3: hipLaunchKernelGGL((layernorm_kernel<T, 3, 2>), grid_for_rpw(2), block, 0, s, (const T*)x, (T*)y, g, b, M, C, eps, silu); break;
+    case 4: case 5: hipLaunchKernelGGL((layernorm_kernel<T, 5, 1>), grid_for_rpw(1), block, 0, s, (const T*)x, (T*)y, g, b, M, C, eps, silu); break;
     default: return -2;
   }
   return hipGetLastError() == hipSuccess ? 0 : -3;
