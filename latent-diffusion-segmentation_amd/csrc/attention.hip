@@ -74,41 +74,43 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
   // K chunk i -> (row i / DCH, chunk i % DCH): coalesced 16-B loads, ds_write_b128 rows.
   // V chunk i -> (row i % 64, chunk i / 64): a wave writes 64 consecutive keys of one d row of
   // V^T, i.e. consecutive 2-/4-byte LDS addresses - no bank conflicts in the transpose.
-  uint4 kreg[KIT], vreg[KIT];
-  auto prefetch = [&](int t) {
-    const int kv0 = t * BKV;
-#pragma unroll
-    for (int it = 0; it < KIT; ++it) {
-      const int i = tid + it * 256;
-      if (it + 1 < KIT || i < NCH) {
-        // rows past N are clamped to the last key: their scores are masked to -inf below, so the
-        // (finite) duplicate K/V data never contributes
-        const int krow = i / Cfg::DCH, kch = i - krow * Cfg::DCH;
-        kreg[it] = *(const uint4*)(kbase + (size_t)min(kv0 + krow, N - 1) * ldb + kch * 16);
-        const int vrow = i & (BKV - 1), vch = i / BKV;
-        vreg[it] = *(const uint4*)(vbase + (size_t)min(kv0 + vrow, N - 1) * ldb + vch * 16);
-      }
-    }
-  };
-  auto commit = [&](int stage) {
-    unsigned char* Ks = smem + stage * STAGE;
-    unsigned char* Vt = Ks + Cfg::KS_BYTES;
-#pragma unroll
-    for (int it = 0; it < KIT; ++it) {
-      const int i = tid + it * 256;
-      if (it + 1 < KIT || i < NCH) {
-        const int krow = i / Cfg::DCH, kch = i - krow * Cfg::DCH;
-        *(uint4*)(Ks + krow * Cfg::KROW + kch * 16) = kreg[it];
-        const int vrow = i & (BKV - 1), vch = i / BKV;
-        union { uint4 u; T e[PC]; } cv;
-        cv.u = vreg[it];
-#pragma unroll
-        for (int k = 0; k < PC; ++k) *(T*)(Vt + (vch * PC + k) * Cfg::VROW + vrow * sizeof(T)) = cv.e[k];
-      }
-    }
-  };
+  // Two register sets (A, B) so that two K/V tiles can be in flight.  The bodies are macros over
+  // the set name: passing the arrays by reference into lambdas made hipcc index them dynamically
+  // (-> scratch memory, 6x slower).
+  u32x4 kregA[KIT], vregA[KIT], kregB[KIT], vregB[KIT];
+#define ATTN_PREFETCH(T_, KR, VR)                                                                          \
+  {                                                                                                        \
+    const int kv0_ = (T_) * BKV;                                                                           \
+    _Pragma("unroll") for (int it = 0; it < KIT; ++it) {                                                   \
+      const int i = tid + it * 256;                                                                        \
+      if (it + 1 < KIT || i < NCH) {                                                                       \
+        /* rows past N are clamped to the last key: their scores are masked to -inf below, so the */      \
+        /* (finite) duplicate K/V data never contributes */                                                \
+        const int krow = i / Cfg::DCH, kch = i - krow * Cfg::DCH;                                          \
+        KR[it] = *(const u32x4*)(kbase + (size_t)min(kv0_ + krow, N - 1) * ldb + kch * 16);                \
+        const int vrow = i & (BKV - 1), vch = i / BKV;                                                     \
+        VR[it] = *(const u32x4*)(vbase + (size_t)min(kv0_ + vrow, N - 1) * ldb + vch * 16);                \
+      }                                                                                                    \
+    }                                                                                                      \
+  }
+#define ATTN_COMMIT(STAGE_, KR, VR)                                                                        \
+  {                                                                                                        \
+    unsigned char* Ks_ = smem + (STAGE_) * STAGE;                                                          \
+    unsigned char* Vt_ = Ks_ + Cfg::KS_BYTES;                                                              \
+    _Pragma("unroll") for (int it = 0; it < KIT; ++it) {                                                   \
+      const int i = tid + it * 256;                                                                        \
+      if (it + 1 < KIT || i < NCH) {                                                                       \
+        const int krow = i / Cfg::DCH, kch = i - krow * Cfg::DCH;                                          \
+        *(u32x4*)(Ks_ + krow * Cfg::KROW + kch * 16) = KR[it];                                             \
+        const int vrow = i & (BKV - 1), vch = i / BKV;                                                     \
+        const u32x4 vv_ = VR[it];                                                                          \
+        _Pragma("unroll") for (int k = 0; k < PC; ++k)                                                     \
+            *(T*)(Vt_ + (vch * PC + k) * Cfg::VROW + vrow * sizeof(T)) = chunk_elem<T>(vv_, k);            \
+      }                                                                                                    \
+    }                                                                                                      \
+  }
 
-  prefetch(0);
+  ATTN_PREFETCH(0, kregA, vregA)
   // zero the whole LDS once: K pad chunks (d >= D), V^T rows d >= D and row pads stay zero
   for (int i = tid * 16; i < NST * STAGE; i += 256 * 16) *(uint4*)(smem + i) = make_uint4(0, 0, 0, 0);
 
@@ -150,11 +152,14 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
     else krow_f[f] = 16 * f + lq;
   }
 
+  const int ntiles = (N + BKV - 1) / BKV;
+  const int nfull = N / BKV;                 // tiles without masked keys
   __syncthreads();
-  commit(0);
+  ATTN_COMMIT(0, kregA, vregA)
+  if (NST == 2 && ntiles > 1) ATTN_PREFETCH(1, kregA, vregA)
   __syncthreads();
 
-  auto tile = [&](int kv0, int stage, auto ragged_tag) {
+  auto tile = [&](int kv0, int stage, auto ragged_tag) __attribute__((always_inline)) {
     constexpr bool RAGGED = decltype(ragged_tag)::value;
     const unsigned char* Ks = smem + stage * STAGE;
     const unsigned char* Vt = Ks + Cfg::KS_BYTES;
@@ -245,23 +250,40 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
     }
   };
 
-  const int ntiles = (N + BKV - 1) / BKV;
-  const int nfull = N / BKV;                 // tiles without masked keys
-  for (int t = 0; t < ntiles; ++t) {
-    const bool more = t + 1 < ntiles;
-    if (more) prefetch(t + 1);
-    const int st = (NST == 2) ? (t & 1) : 0;
+  auto run_tile = [&](int t, int st) __attribute__((always_inline)) {
     if (t < nfull) tile(t * BKV, st, std::false_type{});
     else tile(t * BKV, st, std::true_type{});
-    if constexpr (NST == 2) {
-      if (more) commit(st ^ 1);   // the other stage was last read before the previous barrier
+  };
+  if constexpr (NST == 2) {
+    // K/V tiles are fetched TWO tiles ahead into alternating register sets (the L2 round trip is
+    // longer than one tile of work at 2-3 waves/SIMD) and committed to the free LDS stage one tile
+    // ahead.  Invariant at the top of the even half: stage 0 holds tile t, set A holds tile t+1.
+    int t = 0;
+    for (; t + 1 < ntiles; t += 2) {
+      if (t + 2 < ntiles) ATTN_PREFETCH(t + 2, kregB, vregB)
+      run_tile(t, 0);
+      ATTN_COMMIT(1, kregA, vregA)
       __syncthreads();
-    } else if (more) {
-      __syncthreads();
-      commit(0);
+      if (t + 3 < ntiles) ATTN_PREFETCH(t + 3, kregA, vregA)
+      run_tile(t + 1, 1);
+      if (t + 2 < ntiles) ATTN_COMMIT(0, kregB, vregB)
       __syncthreads();
     }
+    if (t < ntiles) run_tile(t, 0);
+  } else {
+    for (int t = 0; t < ntiles; ++t) {
+      const bool more = t + 1 < ntiles;
+      if (more) ATTN_PREFETCH(t + 1, kregA, vregA)
+      run_tile(t, 0);
+      if (more) {
+        __syncthreads();
+        ATTN_COMMIT(0, kregA, vregA)
+        __syncthreads();
+      }
+    }
   }
+#undef ATTN_PREFETCH
+#undef ATTN_COMMIT
 
   // ---- normalise and store: lane (q, g) holds d = df*16 + 4g + r ----
 #pragma unroll

@@ -8,6 +8,7 @@
 namespace ldmseg {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // native 16-B register chunk (HIP's uint4 struct can end up in scratch)
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short bf16_t;  // raw bf16 bits
 
@@ -107,6 +108,18 @@ __device__ __forceinline__ float row16_sum(float v) {
 }
 // all-lanes sum of a wave64, result in every lane
 __device__ __forceinline__ float wave64_sum(float v) { return xor32_sum(xor16_sum(row16_sum(v))); }
+
+// k-th storage element of a 16-byte chunk (k must fold to a constant after unrolling); avoids
+// union/array punning, which hipcc leaves in scratch memory
+template <typename T> __device__ __forceinline__ T chunk_elem(const u32x4 c, int k);
+template <> __device__ __forceinline__ float chunk_elem<float>(const u32x4 c, int k) {
+  const uint32_t w = c[k];
+  return bits_f32(w);
+}
+template <> __device__ __forceinline__ bf16_t chunk_elem<bf16_t>(const u32x4 c, int k) {
+  const uint32_t w = c[k >> 1];
+  return (bf16_t)((k & 1) ? (w >> 16) : (w & 0xffffu));
+}
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 // erf-GELU (torch.nn.functional.gelu default).  erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7,
