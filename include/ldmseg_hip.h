@@ -170,6 +170,8 @@ int ldmseg_profile_read(int family, int64_t* launches, double* total_ms, double*
 int ldmseg_profile_reset(void);
 /* one CSV line per recorded launch (family,label,ms,flops); label carries the launch shape */
 int ldmseg_profile_dump(const char* path);
+/* tuning knobs for experiments; key 0 = igemm K-loop ring depth (2 | 3 | 4) */
+int ldmseg_debug_set(int key, int value);
 
 #ifdef __cplusplus
 }

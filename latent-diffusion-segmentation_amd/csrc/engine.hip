@@ -1091,6 +1091,13 @@ int ldmseg_profile_read(int family, int64_t* launches, double* total_ms, double*
   return 0;
 }
 
+// tuning knobs for experiments: key 0 = igemm K-loop ring depth (2, 3, 4)
+int ldmseg_debug_set(int key, int value) {
+  if (key == 0) { igemm_set_nbuf(value); return 0; }
+  if (key == 1) { igemm_set_dbg(value); return 0; }   // bits 0-7 ablation flags, bits 8-9 tile policy
+  return fail(LDMSEG_E_ARG, "unknown debug key");
+}
+
 // one CSV line per recorded launch: family,label,ms,flops
 int ldmseg_profile_dump(const char* path) {
   g_err.clear();

@@ -23,6 +23,8 @@
 //    per K tile; 2 workgroups per CU.  Out-of-image taps read a 16-B page of zeros.
 //  * workgroup id -> (m tile, n tile) is remapped so that each XCD (own L2)
 //    owns a contiguous range of tiles.
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -66,9 +68,19 @@ struct RowInfo {
   int iy0, ix0;  // top-left input coordinate (logical, before upsample shift)
 };
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(kThreads) void igemm_kernel(const IgemmParams p) {
-  static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
+}
+
+// NST = number of LDS stages (full K tiles) in the ring.  In iteration kt every wave issues the DMA
+// of tile kt+NST-1 into the stage that was read in iteration kt-1, computes tile kt, then waits
+// with a COUNTED vmcnt until tile kt+1 has landed (NST-2 later tiles stay in flight) and hits the
+// one barrier of the iteration.
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int NST>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(const IgemmParams p) {
+  constexpr int NW = WAVES_M * WAVES_N;   // 4 waves (128-row tiles, 2 workgroups/CU) or 8 (256-row tiles)
+  static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
   constexpr int BKE = kRowBytes / (int)sizeof(T);  // K elements per tile
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
   constexpr int MF = WTM / 16, NF = WTN / 16;
@@ -78,7 +90,7 @@ __global__ __launch_bounds__(kThreads) void igemm_kernel(const IgemmParams p) {
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
   // ---- XCD-aware tile assignment (bijective for any grid size) ----
@@ -110,16 +122,18 @@ __global__ __launch_bounds__(kThreads) void igemm_kernel(const IgemmParams p) {
   // ---- direct-to-LDS staging (global_load_lds_dwordx4): one wave instruction fills one 8-row
   // group (1 KiB, lane l -> row l>>3, physical chunk l&7).  The XOR swizzle therefore lives on the
   // SOURCE side: the lane fetches logical chunk (l&7)^(row&7).  Rows 0..BM-1 of a stage are X,
-  // rows BM.. are W; group g of instruction i belongs to wave (g & 3).
-  constexpr int XG = BM / 32;                  // X groups per wave per tile
-  constexpr int WG = BN / 32;                  // W groups per wave per tile
-  static_assert(BM % 32 == 0 && BN % 32 == 0, "tile rows must be a multiple of 32");
+  // rows BM.. are W; group g = i*NW + wave belongs to wave (g % NW).
+  constexpr int XG = BM / 8 / NW;              // X groups per wave per tile
+  constexpr int WGN = BN / 8;                  // W groups per tile
+  constexpr int WG = (WGN + NW - 1) / NW;      // W rounds; the last one may cover only waves < WREM
+  constexpr int WREM = WGN % NW;
+  static_assert(BM % (8 * NW) == 0 && BN % 8 == 0, "tile rows / loader mismatch");
   const int ld_r = lane >> 3;                  // row within the 8-row group (== row & 7)
   const int ld_j = (lane & 7) ^ ld_r;          // logical 16-B chunk this lane fetches
   RowInfo ri[XG];
 #pragma unroll
   for (int i = 0; i < XG; ++i) {
-    const int m = m0 + (i * 4 + wave) * 8 + ld_r;
+    const int m = m0 + (i * NW + wave) * 8 + ld_r;
     if (m < p.M) {
       const int b = m / HWo, rem = m - b * HWo;
       const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
@@ -137,7 +151,8 @@ __global__ __launch_bounds__(kThreads) void igemm_kernel(const IgemmParams p) {
   unsigned woff[WG];
 #pragma unroll
   for (int i = 0; i < WG; ++i)
-    woff[i] = (unsigned)(((size_t)(i * 32 + wave * 8 + ld_r) * K) * sizeof(T)) + (unsigned)ld_j * 16u;
+    woff[i] = (unsigned)(((size_t)((i * NW + wave) * 8 + ld_r) * K) * sizeof(T)) + (unsigned)ld_j * 16u;
+  const bool w_last = (WREM == 0) || (wave < WREM);   // owns a group in the last W round (wave-uniform)
   const unsigned char* zpage = (const unsigned char*)p.zeros;
   // wave-uniform LDS byte address of this wave's first group in stage 0
   const unsigned lds_wave = __builtin_amdgcn_readfirstlane(
@@ -181,13 +196,14 @@ __global__ __launch_bounds__(kThreads) void igemm_kernel(const IgemmParams p) {
     const unsigned dst = lds_wave + (unsigned)stage * (unsigned)kStageBytes;
 #pragma unroll
     for (int i = 0; i < XG; ++i) {
-      glds16(rowptr[i], dst + i * 4096);
+      glds16(rowptr[i], dst + i * (NW * 1024));
       rowptr[i] += rowinc[i];
     }
     const unsigned char* wt = wtile0 + (size_t)kt * kRowBytes;
     const unsigned wdst = dst + BM * kRowBytes;
 #pragma unroll
-    for (int i = 0; i < WG; ++i) glds16_sbase(woff[i], wt, wdst + i * 4096);
+    for (int i = 0; i < WG; ++i)
+      if (i + 1 < WG || w_last) glds16_sbase(woff[i], wt, wdst + i * (NW * 1024));
     f_cc += BKE;
     if (f_cc == Ctot) { f_cc = 0; ++f_tap; }
     need_setup = (f_cc == 0) | (f_cc == p.C0);
@@ -204,13 +220,33 @@ __global__ __launch_bounds__(kThreads) void igemm_kernel(const IgemmParams p) {
   const int fr_c0 = (((lane >> 4)) ^ (lane & 7)) * 16;
   const int fr_c1 = (((lane >> 4) + 4) ^ (lane & 7)) * 16;
 
-  if (kt_begin < kt_end) fetch(kt_begin, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // wait until at most AHEAD of this wave's per-tile DMA batches are still in flight
+  auto wait_dma = [&](auto ahead_tag) __attribute__((always_inline)) {
+    constexpr int AHEAD = decltype(ahead_tag)::value;
+    if constexpr (AHEAD == 0) {
+      wait_vmcnt<0>();
+    } else if constexpr (WREM == 0) {
+      wait_vmcnt<AHEAD*(XG + WG)>();
+    } else {
+      if (w_last) wait_vmcnt<AHEAD*(XG + WG)>();
+      else wait_vmcnt<AHEAD*(XG + WG - 1)>();
+    }
+  };
+
+  // ---- prologue: NST-1 tiles in flight, the first one landed ----
+  const int nkt = kt_end - kt_begin;
+#pragma unroll
+  for (int j = 0; j < NST - 1; ++j)
+    if (j < nkt) fetch(kt_begin + j, j);
+  if (nkt >= NST - 1) wait_dma(std::integral_constant<int, NST - 2>{});
+  else wait_dma(std::integral_constant<int, 0>{});
   __syncthreads();
 
+  int cur = 0;            // stage of tile kt
+  int fst = NST - 1;      // stage the next DMA goes to
   for (int kt = kt_begin; kt < kt_end; ++kt) {
-    const int cur = (kt - kt_begin) & 1;
-    if (kt + 1 < kt_end) fetch(kt + 1, cur ^ 1);   // DMA of the next tile flies under this tile's MFMAs
+    const bool more = (kt + NST - 1 < kt_end);
+    if (more && !(p.dbg & 1)) fetch(kt + NST - 1, fst);
     const unsigned char* xs = smem + cur * kStageBytes + (wm * WTM) * kRowBytes + fr_row;
     const unsigned char* ws = smem + cur * kStageBytes + (BM + wn * WTN) * kRowBytes + fr_row;
 #pragma unroll
@@ -221,13 +257,24 @@ __global__ __launch_bounds__(kThreads) void igemm_kernel(const IgemmParams p) {
       for (int a = 0; a < NF; ++a) wf[a] = *(const uint4*)(ws + a * 16 * kRowBytes + co);
 #pragma unroll
       for (int b = 0; b < MF; ++b) xf[b] = *(const uint4*)(xs + b * 16 * kRowBytes + co);
+      if (!(p.dbg & 4)) {
 #pragma unroll
-      for (int a = 0; a < NF; ++a)
+        for (int a = 0; a < NF; ++a)
 #pragma unroll
-        for (int b = 0; b < MF; ++b) mma_kgroup<T>(wf[a], xf[b], acc[a][b]);
+          for (int b = 0; b < MF; ++b) mma_kgroup<T>(wf[a], xf[b], acc[a][b]);
+      } else {
+#pragma unroll
+        for (int a = 0; a < NF; ++a) asm volatile("" ::"v"(wf[a].x), "v"(wf[a].w));
+#pragma unroll
+        for (int b = 0; b < MF; ++b) asm volatile("" ::"v"(xf[b].x), "v"(xf[b].w));
+      }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of tile kt+1 have landed
-    __syncthreads();                                    // ... and everybody's; stage `cur` is free again
+    // tile kt+1 must have landed before anyone reads it; later tiles may stay in flight
+    if (more) wait_dma(std::integral_constant<int, NST - 2>{});
+    else wait_dma(std::integral_constant<int, 0>{});
+    __syncthreads();
+    cur = (cur + 1 == NST) ? 0 : cur + 1;
+    fst = (fst + 1 == NST) ? 0 : fst + 1;
   }
 
   // ---- epilogue: lane holds n = nb + 4*(lane>>4) + r (r=0..3) of m = mb + (lane&15) ----
@@ -360,21 +407,26 @@ const void* zero_page() {
   return z;
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
+int g_dbg = 0;       // ablation flags (profiling experiments only)
+int g_big = 1;       // bit0: 8-wave 256-row tiles with a 3-stage ring (-0.15 ms per forward, on);
+                     // bit1: 4-stage ring, one workgroup per CU, for mid-size grids (+0.5 ms, off)
+
+template <typename T, int BM, int BN, int WM, int WN, int NST = 2>
 int run(const IgemmParams& pin, hipStream_t s) {
   IgemmParams p = pin;
+  p.dbg = g_dbg;
   p.zeros = zero_page();
   if (!p.zeros) return -3;
   const int mt = (p.M + BM - 1) / BM, nt = p.N / BN;
-  const size_t lds = 2 * (size_t)(BM + BN) * kRowBytes;
-  auto kern = igemm_kernel<T, BM, BN, WM, WN>;
+  const size_t lds = (size_t)NST * (BM + BN) * kRowBytes;
+  auto kern = igemm_kernel<T, BM, BN, WM, WN, NST>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   dim3 grid(mt * nt, p.splits > 1 ? p.splits : 1);
-  hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, s, p);
+  hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, s, p);
   if (p.splits > 1) {
     const size_t total = (size_t)p.M * (p.n_valid >> 2);
     int blocks = (int)((total + 255) / 256);
@@ -390,15 +442,31 @@ int dispatch(const IgemmParams& p, hipStream_t s) {
   // fewer than ~1.5 workgroups per CU with 128-row tiles: halve the M tile (2 co-resident
   // workgroups per CU are what hides the per-K-tile barrier)
   const bool small = (long)((p.M + 127) / 128) * (p.N / bn) < 400;
+  // plenty of rows: 256-row tiles / 8 waves cut the operand bytes staged per FLOP (the K loop is
+  // bound by global->LDS traffic, not by MFMA issue) as long as every CU still gets a workgroup
+  // (the global->LDS path tops out near 12 TB/s chip-wide, i.e. needs ~70 KB in flight per CU).
+  // One workgroup per CU then has to keep two tiles in flight itself: a 3-stage ring.
+  const long t256 = (long)((p.M + 255) / 256) * (p.N / bn);
+  const long t128 = (long)((p.M + 127) / 128) * (p.N / bn);
+  const bool big = (g_big & 1) && t256 >= 240;
+  // 128-row tiles that cannot put two workgroups on every CU: deeper ring, one workgroup per CU
+  const bool deep = (g_big & 2) && !big && t128 >= 200 && t128 < 400;
   switch (bn) {
-    case 160: return small ? run<T, 64, 160, 2, 2>(p, s) : run<T, 128, 160, 2, 2>(p, s);
-    case 128: return small ? run<T, 64, 128, 2, 2>(p, s) : run<T, 128, 128, 2, 2>(p, s);
+    case 160:
+      return big ? run<T, 256, 160, 4, 2, 3>(p, s) : deep ? run<T, 128, 160, 2, 2, 4>(p, s)
+                 : small ? run<T, 64, 160, 2, 2>(p, s) : run<T, 128, 160, 2, 2>(p, s);
+    case 128:
+      return big ? run<T, 256, 128, 4, 2, 3>(p, s) : deep ? run<T, 128, 128, 2, 2, 4>(p, s)
+                 : small ? run<T, 64, 128, 2, 2>(p, s) : run<T, 128, 128, 2, 2>(p, s);
     case 64: return run<T, 128, 64, 4, 1>(p, s);
     default: return run<T, 128, 32, 4, 1>(p, s);
   }
 }
 
 }  // namespace
+
+void igemm_set_nbuf(int) {}
+void igemm_set_dbg(int f) { g_dbg = f & 0xff; g_big = (f >> 8) & 3; }   // bits 8-9 select the tile policy
 
 int igemm_pick_bn(int n_real, int epi) {
   if (epi == EPI_GEGLU) return 128;

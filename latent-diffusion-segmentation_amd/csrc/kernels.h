@@ -43,12 +43,15 @@ struct IgemmParams {
   int splits = 1;
   float* partial = nullptr;
   const void* zeros = nullptr;   // >= 16 B of zeros (set by the launcher)
+  int dbg = 0;                   // ablation flags for profiling experiments (results are wrong when != 0)
 };
 
 // returns 0 or a negative error (bad shape)
 int launch_igemm(const IgemmParams& p, int dtype, hipStream_t s);
 size_t igemm_partial_bytes(const IgemmParams& p);
 int igemm_plan_splits(const IgemmParams& p, int dtype);
+void igemm_set_nbuf(int n);
+void igemm_set_dbg(int flags);   // ablation flags (profiling only)   // K-loop ring depth (2, 3, 4) - tuning knob
 // tile the launcher would pick (for weight padding): N tile size for a given N.
 int igemm_pick_bn(int n_real, int epi);
 

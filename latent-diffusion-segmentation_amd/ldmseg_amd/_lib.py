@@ -60,6 +60,7 @@ SIGNATURES = {
     "ldmseg_profile_read": (_i, [_i, C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "ldmseg_profile_reset": (_i, []),
     "ldmseg_profile_dump": (_i, [C.c_char_p]),
+    "ldmseg_debug_set": (_i, [_i, _i]),
     # include/ldmseg_hip_ops.h
     "ldmseg_op_conv2d": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "ldmseg_op_linear": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),

@@ -205,3 +205,24 @@ def test_convt2_and_bilinear(L, dt):
     assert L.lib().ldmseg_op_bilinear2x(P(dy), 2, 128, 5, 9, dt, P(out), None) == 0
     torch.cuda.synchronize()
     assert rel_err(out, ref) < 1e-5
+
+
+@pytest.mark.parametrize("policy", [0, 1, 2, 3])
+def test_igemm_tile_policies_agree(L, policy):
+    """The alternative K-loop structures (8-wave 256-row tiles with a 3-stage LDS ring, 4-stage ring
+    for mid-size grids) are selectable tuning knobs; they must all give the reference result."""
+    B, Ci, H, Co = 8, 128, 64, 160        # M = 32768 rows: enough tiles for every policy to engage
+    g = torch.Generator().manual_seed(policy)
+    x = torch.randn(B, Ci, H, H, generator=g)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / (Ci * 9) ** 0.5
+    b = torch.randn(Co, generator=g)
+    ref = F.conv2d(bf16_round(x), bf16_round(w), b, padding=1)
+    out = torch.empty(ref.shape, device="cuda")
+    dx, dw, db = dev(x), dev(w), dev(b)
+    try:
+        assert L.lib().ldmseg_debug_set(1, policy << 8) == 0
+        assert L.lib().ldmseg_op_conv2d(P(dx), None, P(dw), P(db), B, Ci, 0, H, H, Co, 3, 1, 0, BF16, P(out), None) == 0
+        torch.cuda.synchronize()
+    finally:
+        L.lib().ldmseg_debug_set(1, 1 << 8)   # default policy
+    assert rel_err(out, ref) < 1e-3
