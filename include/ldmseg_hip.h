@@ -158,6 +158,14 @@ typedef struct {
 int ldmseg_sample_loop(ldmseg_unet* h, const ldmseg_sample_cfg* cfg, float* latents, const float* rgb_latents,
                        int B, int L, float* all_latents, void* stream);
 
+/* ---- bit codec of segment ids: COCO.encode_bitmap / decode_bitmap (ldmseg/data/coco.py:377-390) ---- */
+/* ids [B,HW] int64 -> bits [B,n_bits,HW] fp32 (LSB first; ids == ignore_label -> fill_value), then *mul+add
+ * (mul=2, add=-1 gives the seg-VAE input of trainers_ldm_cond.py:369); ignore_mask [B,HW] u8 may be NULL. */
+int ldmseg_bit_encode(const int64_t* ids, int B, int n_bits, int HW, int64_t ignore_label, float fill_value, float mul,
+                      float add, float* bits, uint8_t* ignore_mask, void* stream);
+/* x [B,n_bits,HW] fp32 -> ids [B,HW] int64: bit k set iff x[:,k] > 0 */
+int ldmseg_bit_decode(const float* x, int B, int n_bits, int HW, int64_t* ids, void* stream);
+
 /* ---- diagnostics --------------------------------------------------------------------------- */
 const char* ldmseg_last_error(void);
 const char* ldmseg_version(void);

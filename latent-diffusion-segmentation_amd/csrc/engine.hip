@@ -1058,6 +1058,20 @@ int ldmseg_sample_loop(ldmseg_unet* h, const ldmseg_sample_cfg* cfg, float* late
   return 0;
 }
 
+int ldmseg_bit_encode(const int64_t* ids, int B, int n_bits, int HW, int64_t ignore_label, float fill_value, float mul,
+                      float add, float* bits, uint8_t* ignore_mask, void* stream) {
+  g_err.clear();
+  if (!ids || !bits || n_bits < 1 || n_bits > 31) return fail(LDMSEG_E_ARG, "bad bit_encode argument");
+  TRY(launch_bit_encode(ids, bits, ignore_mask, B, n_bits, HW, ignore_label, fill_value, mul, add, (hipStream_t)stream));
+  return 0;
+}
+int ldmseg_bit_decode(const float* x, int B, int n_bits, int HW, int64_t* ids, void* stream) {
+  g_err.clear();
+  if (!x || !ids || n_bits < 1 || n_bits > 24) return fail(LDMSEG_E_ARG, "bad bit_decode argument");
+  TRY(launch_bit_decode(x, ids, B, n_bits, HW, (hipStream_t)stream));
+  return 0;
+}
+
 int ldmseg_profile_enable(int enable) {
   g_prof.on = enable != 0;
   return 0;

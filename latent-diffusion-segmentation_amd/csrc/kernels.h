@@ -110,6 +110,10 @@ int launch_inpaint_paste(float* cur, const float* z0, const float* noise, const 
 int launch_add_noise(const float* x0, const float* noise, const int64_t* t_dev, const float* ac_dev, float scale,
                      float* out, int B, size_t per, int remove, hipStream_t s);
 int launch_axpby(const float* x, float a, float b, float* y, size_t n, hipStream_t s);  // y = a*x + b
+// bit codec of segment ids (ldmseg/data/coco.py:377-390)
+int launch_bit_encode(const int64_t* ids, float* out, uint8_t* ignore, int B, int n, int HW, int64_t ignore_label,
+                      float fill, float mul, float add, hipStream_t s);
+int launch_bit_decode(const float* x, int64_t* out, int B, int n, int HW, hipStream_t s);
 // mean + exp(0.5*clamp(logvar))*noise on NCHW moments [B,8,HW] -> [B,4,HW]
 int launch_posterior_sample(const float* moments, const float* noise, float* out, int B, int HW, hipStream_t s);
 

@@ -138,6 +138,33 @@ __global__ void repack_convt2_kernel(const float* w, T* out, int Ci, int Co) {
   }
 }
 
+// COCO.encode_bitmap (ldmseg/data/coco.py:377-382): ids [B,HW] int64 -> bits [B,n,HW] f32, LSB first,
+// ignore_label pixels -> fill_value; optional affine (2x-1 of encode_inputs) and ignore mask.
+__global__ void bit_encode_kernel(const int64_t* ids, float* out, uint8_t* ignore, int n, int HW, size_t total,
+                                  int64_t ignore_label, float fill, float mul, float add) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = i / HW, pix = i - b * HW;
+    const int64_t v = ids[i];
+    const bool ign = (v == ignore_label);
+    if (ignore) ignore[i] = ign ? 1 : 0;
+    for (int k = 0; k < n; ++k) {
+      // torch.remainder(x >> k, 2): python-style modulo, also for negative ids
+      const int64_t sh = v >> k;
+      const float bit = (float)(sh & 1);
+      out[(b * n + k) * HW + pix] = (ign ? fill : bit) * mul + add;
+    }
+  }
+}
+// COCO.decode_bitmap (coco.py:384-390): x [B,n,HW] f32 -> ids [B,HW] int64, bit k set iff x[k] > 0
+__global__ void bit_decode_kernel(const float* x, int64_t* out, int n, int HW, size_t total) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = i / HW, pix = i - b * HW;
+    float acc = 0.f;   // the reference sums float(bit) * 2**k in fp32
+    for (int k = 0; k < n; ++k) acc += (x[(b * n + k) * HW + pix] > 0.f ? 1.f : 0.f) * (float)(1ll << k);
+    out[i] = (int64_t)acc;
+  }
+}
+
 __global__ void posterior_sample_kernel(const float* mom, const float* noise, float* out, int HW, size_t total) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const size_t pix = i % HW, r = i / HW;
@@ -234,6 +261,18 @@ int launch_repack_convt2(const float* w, void* out, int Ci, int Co, int dtype, h
 
 
 
+
+int launch_bit_encode(const int64_t* ids, float* out, uint8_t* ignore, int B, int n, int HW, int64_t ignore_label,
+                      float fill, float mul, float add, hipStream_t s) {
+  const size_t total = (size_t)B * HW;
+  hipLaunchKernelGGL(bit_encode_kernel, dim3(grid_for(total)), dim3(256), 0, s, ids, out, ignore, n, HW, total, ignore_label, fill, mul, add);
+  return ok();
+}
+int launch_bit_decode(const float* x, int64_t* out, int B, int n, int HW, hipStream_t s) {
+  const size_t total = (size_t)B * HW;
+  hipLaunchKernelGGL(bit_decode_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, out, n, HW, total);
+  return ok();
+}
 
 int launch_posterior_sample(const float* moments, const float* noise, float* out, int B, int HW, hipStream_t s) {
   const size_t total = (size_t)B * 4 * HW;

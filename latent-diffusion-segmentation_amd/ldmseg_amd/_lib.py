@@ -54,6 +54,8 @@ SIGNATURES = {
     "ldmseg_add_noise": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _i, _sz, _vp]),
     "ldmseg_remove_noise": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _i, _sz, _vp]),
     "ldmseg_sample_loop": (_i, [_vp, C.POINTER(SampleCfg), _vp, _vp, _i, _i, _vp, _vp]),
+    "ldmseg_bit_encode": (_i, [_vp, _i, _i, _i, _i64, _f, _f, _f, _vp, _vp, _vp]),
+    "ldmseg_bit_decode": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "ldmseg_last_error": (C.c_char_p, []),
     "ldmseg_version": (C.c_char_p, []),
     "ldmseg_profile_enable": (_i, [_i]),

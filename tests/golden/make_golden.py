@@ -178,6 +178,34 @@ def loop_golden(DDIM):
     print("sample_loop.npz ok")
 
 
+def bitcodec_golden():
+    """COCO.encode_bitmap / decode_bitmap (ldmseg/data/coco.py:377-390), called unbound with a dummy
+    self (ignore_label = 0) as SURVEY App. C describes; torchvision is stubbed AFTER transformers."""
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+    mod("torchvision"); mod("torchvision.transforms", Compose=object, InterpolationMode=object)
+    mod("torchvision.transforms.functional")
+    for name in ("termcolor", "wandb"):
+        if name not in sys.modules:
+            mod(name, colored=lambda s, *a, **k: s)
+    from ldmseg.data.coco import COCO
+    dummy = types.SimpleNamespace(ignore_label=0)
+    g = torch.Generator().manual_seed(17)
+    ids = torch.randint(0, 128, (24, 40), generator=g)
+    ids[:3, :5] = 0                                   # void region
+    ids[5, 7] = 127
+    bits, ignore = COCO.encode_bitmap(dummy, ids.clone())
+    dec = COCO.decode_bitmap(dummy, 2.0 * bits - 1.0)
+    out = {"ids": ids.numpy(), "bits": bits.numpy(), "ignore": ignore.numpy(), "decoded": dec.numpy()}
+    logits = torch.randn((7, 24, 40), generator=g)
+    out["dec_in"] = logits.numpy()
+    out["dec_out"] = COCO.decode_bitmap(dummy, logits).numpy()
+    np.savez_compressed(os.path.join(HERE, "bitcodec.npz"), **out)
+    print("bitcodec.npz ok", bits.shape, dec.dtype)
+
+
 def main():
     if not os.path.isdir(REF):
         print("reference not present; nothing to do")
@@ -190,6 +218,10 @@ def main():
     scheduler_golden(DDIMNoiseScheduler)
     vae_golden(GeneralVAESeg)
     loop_golden(DDIMNoiseScheduler)
+    try:
+        bitcodec_golden()
+    except Exception as e:   # the dataset module drags in many optional deps
+        print('bitcodec golden skipped:', repr(e))
 
 
 if __name__ == "__main__":

@@ -1,0 +1,53 @@
+"""CPU suite, part 3: bit-codec oracle against the reference-generated golden, and the readers for
+the reference's checkpoint layouts (host logic only)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import bitcodec as o_bits
+
+
+def test_bitcodec_oracle_vs_reference_golden(golden):
+    g = golden("bitcodec.npz")
+    bits, ign = o_bits.encode_bitmap(g["ids"])
+    assert np.array_equal(bits, g["bits"]) and np.array_equal(ign, g["ignore"])
+    assert np.array_equal(o_bits.decode_bitmap(2 * g["bits"] - 1), g["decoded"])
+    assert np.array_equal(o_bits.decode_bitmap(g["dec_in"]), g["dec_out"])
+    # SURVEY App. C known answers: id 1 -> [1,0,0,0,0,0,0], id 5 -> [1,0,1,...], 127 -> ones, void -> 0.5
+    b, _ = o_bits.encode_bitmap(np.array([[0, 1, 2], [5, 127, 64]]))
+    assert b[:, 0, 1].tolist() == [1, 0, 0, 0, 0, 0, 0]
+    assert b[:, 1, 0].tolist() == [1, 0, 1, 0, 0, 0, 0]
+    assert b[:, 1, 1].tolist() == [1] * 7 and b[:, 0, 0].tolist() == [0.5] * 7
+    assert o_bits.decode_bitmap(2 * b - 1).tolist() == [[0, 1, 2], [5, 127, 64]]
+
+
+def _tiny_like(schema):
+    # tensors with the right shapes but shared zero storage (cheap): the loader only checks keys/shapes
+    return {k: torch.zeros(1).expand(shp) for k, shp in schema.items()}
+
+
+def test_checkpoint_readers(tmp_path):
+    from ldmseg_amd import checkpoint, weights
+    usd = _tiny_like(weights.unet_schema(12, False))
+    usd["new_conv.weight"] = usd["conv_in.weight"]            # duplicate alias the reference saves (unet.py:182,233)
+    usd["new_conv.bias"] = usd["conv_in.bias"]
+    vsd = weights.generate(weights.vae_schema(), seed=1, norm_keys=weights.VAE_NORM_KEYS)
+    data = {"step": 7, "epoch": 1, "vae_image": {}, "vae_semseg": vsd, "unet": usd, "ema": None, "opt": None,
+            "p": {"x": 1}, "scaler": None}
+    out = checkpoint.unet_state_from(data)
+    assert list(out) == list(weights.unet_schema(12, False)) and "new_conv.weight" not in out
+    assert list(checkpoint.vae_state_from(data)) == list(weights.vae_schema())
+    ae = {"step": 1, "epoch": 0, "vae": {"module." + k: v for k, v in vsd.items()}, "opt": None, "p": {}, "scaler": None}
+    path = tmp_path / "ae.pt"
+    torch.save(ae, str(path))
+    back = checkpoint.load_ae_checkpoint(str(path))
+    assert all(torch.equal(back[k], vsd[k]) for k in vsd)
+    bad = dict(data, unet={k: v for k, v in usd.items() if k != "conv_out.bias"})
+    with pytest.raises(KeyError):
+        checkpoint.unet_state_from(bad)
+    bad = dict(data, unet=dict(usd, **{"conv_out.bias": torch.zeros(5)}))
+    with pytest.raises(ValueError):
+        checkpoint.unet_state_from(bad)
+    cross = dict(usd, **{"mid_block.attentions.0.transformer_blocks.0.attn2.to_q.weight": torch.zeros(1)})
+    with pytest.raises(NotImplementedError):
+        checkpoint.unet_state_from(dict(data, unet=cross))

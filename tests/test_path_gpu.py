@@ -234,3 +234,33 @@ def test_full_size_properties(unets):
     assert rel_err(y_single, y1[2:3]) < 2e-2                        # only the GN chunking differs with B
     tt = torch.full((8,), 499, device=DEV, dtype=torch.int64)
     assert torch.equal(u(x, tt).sample, y1)                         # [B] timesteps == broadcast scalar
+
+
+# ------------------------------------------------------------------ section 8(f) rank 3: bit codec + checkpoint readers
+def test_bitcodec_bit_exact_vs_reference_golden(golden):
+    from ldmseg_amd.data import encode_bitmap, decode_bitmap
+    g = golden("bitcodec.npz")
+    ids = torch.from_numpy(g["ids"]).to(DEV)
+    bits, ign = encode_bitmap(ids)
+    assert np.array_equal(bits.cpu().numpy(), g["bits"]) and np.array_equal(ign.cpu().numpy(), g["ignore"])
+    assert np.array_equal(decode_bitmap(2 * bits - 1).cpu().numpy(), g["decoded"])
+    assert np.array_equal(decode_bitmap(torch.from_numpy(g["dec_in"]).to(DEV)).cpu().numpy(), g["dec_out"])
+    bb, _ = encode_bitmap(ids[None].repeat(3, 1, 1), affine=(2.0, -1.0))          # batched + fused 2x-1
+    assert bb.shape == (3, 7, 24, 40) and torch.equal(bb[1], 2 * bits - 1)
+    big = torch.randint(0, 128, (2, 512, 512), generator=torch.Generator().manual_seed(0)).to(DEV)
+    rt = decode_bitmap(encode_bitmap(big, affine=(2.0, -1.0))[0])                 # full-size round trip (void == 0)
+    assert torch.equal(rt, big)
+
+
+def test_models_from_reference_style_checkpoint(tmp_path, unet_sd, vae_sd, unets):
+    from ldmseg_amd import checkpoint
+    usd = dict(unet_sd)
+    usd["new_conv.weight"], usd["new_conv.bias"] = usd["conv_in.weight"], usd["conv_in.bias"]
+    data = {"step": 1, "epoch": 0, "vae_image": {}, "vae_semseg": {"module." + k: v for k, v in vae_sd.items()},
+            "unet": usd, "ema": None, "opt": None, "p": {}, "scaler": None}
+    state = checkpoint.unet_state_from(data)
+    from ldmseg_amd.models import UNet
+    u = UNet(state, in_channels=12, device=DEV, compute_dtype="fp32")
+    x = torch.randn(1, 12, 16, 16, generator=torch.Generator().manual_seed(5)).to(DEV)
+    assert torch.equal(u(x, 321).sample, unets["fp32"](x, 321).sample)
+    assert list(checkpoint.vae_state_from(data)) == list(vae_sd)
