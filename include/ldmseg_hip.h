@@ -110,6 +110,12 @@ void ldmseg_vae_destroy(ldmseg_vae* h);
  * `z_scale` multiplies z first (decode_latents' 1/scaling_factor, trainers_ldm_cond.py:421). */
 int ldmseg_vae_decode(ldmseg_vae* h, const float* z, float z_scale, int B, int L, int interpolate, float* logits,
                       void* stream);
+/* Fused tail of TrainerDiffusion.decode_latents(return_logits=False, threshold_output) (trainers_ldm_cond.py:
+ * 421-433): decode -> bilinear x2 -> argmax over the 128 classes and max-softmax probability, without writing the
+ * logits.  ids [B,8L,8L] int64 (= ignore_label where max prob < mask_th; mask_th < 0 disables the threshold),
+ * max_prob [B,8L,8L] fp32 or NULL. */
+int ldmseg_vae_decode_argmax(ldmseg_vae* h, const float* z, float z_scale, int B, int L, float mask_th, int64_t ignore_label,
+                             int64_t* ids, float* max_prob, void* stream);
 /* GeneralVAESeg.encode(x) (vae.py:252-265): x [B,7,H,W] (H=W multiple of 8), moments
  * [B,8,H/8,W/8] = (mean | logvar) before the clamp.  x is used as x*in_mul+in_add
  * (encode_inputs' 2x-1, trainers_ldm_cond.py:369). */

@@ -806,8 +806,10 @@ int vae_build(ldmseg_vae* v, const WeightMap& wm) {
   return 0;
 }
 
+struct ArgmaxOut { int64_t* ids = nullptr; float* prob = nullptr; float mask_th = -1.f; int64_t ignore_label = 0; };
+
 int vae_decode_impl(ldmseg_vae* v, const float* z, float z_scale, int B, int L, int interpolate, float* logits,
-                    hipStream_t s, bool dry, size_t scratch_base) {
+                    hipStream_t s, bool dry, size_t scratch_base, const ArgmaxOut* am = nullptr) {
   Workspace* ws = &v->ws;
   ws->begin(dry, scratch_base);
   Exec ex{ws, v->dt, B, s};
@@ -839,7 +841,13 @@ int vae_decode_impl(ldmseg_vae* v, const float* z, float z_scale, int B, int L, 
   p.src0 = g.p; p.C0 = g.C; p.B = B; p.Hi = p.Ho = H4; p.Wi = p.Wo = W4;
   p.taps = 9; p.M = B * H4 * W4; p.N = v->dec_out.N; p.n_valid = c.out_channels;
   p.W = v->dec_out.w; p.bias = v->dec_out.bias;
-  if (!interpolate) {
+  if (am) {   // fused tail: NHWC logits at 4L -> bilinear x2 + argmax + max-softmax, no logits tensor
+    Act lo = ex.new_act(c.out_channels, H4, W4, false);
+    p.out = lo.p; p.ldo = c.out_channels; p.epi = EPI_STORE;
+    TRY(ex.igemm(p));
+    ProfScope ps(4, s, 0, (double)B * H4 * W4 * c.out_channels * esize(dt) + (double)B * 4 * H4 * W4 * 12.0, dry);
+    if (!dry) TRY(launch_bilinear2x_argmax(lo.p, am->ids, am->prob, B, H4, W4, c.out_channels, am->mask_th, am->ignore_label, dt, s));
+  } else if (!interpolate) {
     p.out = logits; p.epi = EPI_NCHW_F32;
     TRY(ex.igemm(p));
   } else {
@@ -969,6 +977,19 @@ int ldmseg_vae_decode(ldmseg_vae* h, const float* z, float z_scale, int B, int L
   const size_t persist = rup(h->ws.persist_peak, 4096), scratch = rup(h->ws.scratch_peak, 4096);
   TRY(ensure_ws(&h->ws_mem, &h->ws_cap, &h->ws, persist + scratch));
   return vae_decode_impl(h, z, z_scale, B, L, interpolate, logits, (hipStream_t)stream, false, persist);
+}
+
+int ldmseg_vae_decode_argmax(ldmseg_vae* h, const float* z, float z_scale, int B, int L, float mask_th, int64_t ignore_label,
+                             int64_t* ids, float* max_prob, void* stream) {
+  g_err.clear();
+  if (!h || !z || !ids) return fail(LDMSEG_E_ARG, "null argument");
+  if (B < 1 || L < 1) return fail(LDMSEG_E_SHAPE, "bad B/L");
+  if (h->cfg.num_upscalers != 2) return fail(LDMSEG_E_ARG, "the fused tail assumes interpolation_factor 2 (num_upscalers 2)");
+  ArgmaxOut am{ids, max_prob, mask_th, ignore_label};
+  TRY(vae_decode_impl(h, z, z_scale, B, L, 1, nullptr, (hipStream_t)stream, true, 0, &am));
+  const size_t persist = rup(h->ws.persist_peak, 4096), scratch = rup(h->ws.scratch_peak, 4096);
+  TRY(ensure_ws(&h->ws_mem, &h->ws_cap, &h->ws, persist + scratch));
+  return vae_decode_impl(h, z, z_scale, B, L, 1, nullptr, (hipStream_t)stream, false, persist, &am);
 }
 
 int ldmseg_vae_encode(ldmseg_vae* h, const float* x, float in_mul, float in_add, int B, int H, float* moments,

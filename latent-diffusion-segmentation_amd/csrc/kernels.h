@@ -91,6 +91,10 @@ int launch_small_linear(const float* x, const float* W, const float* bias, float
 // bilinear x2 (align_corners=False) NHWC compute dtype [B,H,W,C] -> NCHW f32 [B,C,2H,2W]
 int launch_bilinear2x_nchw(const void* x, float* y, int B, int H, int W, int C, int dtype, hipStream_t s);
 
+// fused decode tail: bilinear x2 + argmax over C + max-softmax prob; mask_th < 0 disables the threshold
+int launch_bilinear2x_argmax(const void* x, int64_t* ids, float* prob, int B, int H, int W, int C, float mask_th,
+                             int64_t ignore_label, int dtype, hipStream_t s);
+
 // weight repack (f32 torch layout -> compute dtype [N][K])
 // conv OIHW [Co][Ci][kh][kw] -> [Npad][kh*kw][Cipad] ; rows >= Co and channels >= Ci are zero
 int launch_repack_conv(const float* w, void* out, int Co, int Ci, int KH, int KW, int Npad, int Cipad,

@@ -103,6 +103,54 @@ __global__ __launch_bounds__(256) void bilinear2x_kernel(const T* x, float* y, i
   }
 }
 
+// ---------------------------------------------------------------- fused decode tail
+// bilinear x2 (align_corners=False) of NHWC logits [B,H,W,C] fused with argmax over C and the
+// max-softmax probability (trainers_ldm_cond.py:427-433): ids [B,2H,2W] int64 (ignore_label where
+// prob < mask_th, if mask_th >= 0), prob [B,2H,2W] f32 (optional).  Online softmax: one pass over C,
+// the 134 MB/image fp32 logits tensor is never written.
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_argmax_kernel(const T* x, int64_t* ids, float* prob, int H, int W, int C,
+                                                              float mask_th, int64_t ignore_label) {
+  constexpr int PC = Chunk<T>::N;
+  const int OW = 2 * W, OH = 2 * H;
+  const int ox = blockIdx.x * blockDim.x + threadIdx.x;
+  const int oy = blockIdx.y;
+  const int b = blockIdx.z;
+  if (ox >= OW) return;
+  const float sy = fmaxf(0.5f * (oy + 0.5f) - 0.5f, 0.f), sx = fmaxf(0.5f * (ox + 0.5f) - 0.5f, 0.f);
+  const int y0 = (int)sy, x0 = (int)sx;
+  const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+  const float ly1 = sy - y0, ly0 = 1.f - ly1, lx1 = sx - x0, lx0 = 1.f - lx1;
+  const T* r00 = x + (((size_t)b * H + y0) * W + x0) * C;
+  const T* r01 = x + (((size_t)b * H + y0) * W + x1) * C;
+  const T* r10 = x + (((size_t)b * H + y1) * W + x0) * C;
+  const T* r11 = x + (((size_t)b * H + y1) * W + x1) * C;
+  float m = -INFINITY, ssum = 0.f;
+  int arg = 0;
+  for (int c = 0; c < C; c += PC) {
+    float a[PC], bb[PC], cc[PC], d[PC];
+    Chunk<T>::unpack(*(const uint4*)(r00 + c), a);
+    Chunk<T>::unpack(*(const uint4*)(r01 + c), bb);
+    Chunk<T>::unpack(*(const uint4*)(r10 + c), cc);
+    Chunk<T>::unpack(*(const uint4*)(r11 + c), d);
+#pragma unroll
+    for (int e = 0; e < PC; ++e) {
+      const float v = ly0 * (lx0 * a[e] + lx1 * bb[e]) + ly1 * (lx0 * cc[e] + lx1 * d[e]);
+      if (v > m) {            // strict: the first maximum wins, like torch.argmax
+        ssum = ssum * __expf(m - v) + 1.f;
+        m = v;
+        arg = c + e;
+      } else {
+        ssum += __expf(v - m);
+      }
+    }
+  }
+  const float pmax = 1.f / ssum;
+  const size_t o = ((size_t)b * OH + oy) * OW + ox;
+  ids[o] = (mask_th >= 0.f && pmax < mask_th) ? ignore_label : (int64_t)arg;
+  if (prob) prob[o] = pmax;
+}
+
 // ---------------------------------------------------------------- weight repack
 template <typename T>
 __global__ void repack_conv_kernel(const float* w, T* out, int Co, int Ci, int KH, int KW, int Npad, int Cipad) {
@@ -226,6 +274,19 @@ int launch_bilinear2x_nchw(const void* x, float* y, int B, int H, int W, int C, 
   } else {
     if (C % 4) return -2;
     hipLaunchKernelGGL(bilinear2x_kernel<float>, grid, block, 0, s, (const float*)x, y, H, W, C);
+  }
+  return ok();
+}
+
+int launch_bilinear2x_argmax(const void* x, int64_t* ids, float* prob, int B, int H, int W, int C, float mask_th,
+                             int64_t ignore_label, int dtype, hipStream_t s) {
+  dim3 grid((2 * W + 255) / 256, 2 * H, B), block(256);
+  if (dtype == DT_BF16) {
+    if (C % 8) return -2;
+    hipLaunchKernelGGL(bilinear_argmax_kernel<bf16_t>, grid, block, 0, s, (const bf16_t*)x, ids, prob, H, W, C, mask_th, ignore_label);
+  } else {
+    if (C % 4) return -2;
+    hipLaunchKernelGGL(bilinear_argmax_kernel<float>, grid, block, 0, s, (const float*)x, ids, prob, H, W, C, mask_th, ignore_label);
   }
   return ok();
 }

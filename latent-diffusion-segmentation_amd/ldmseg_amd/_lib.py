@@ -47,6 +47,7 @@ SIGNATURES = {
     "ldmseg_vae_create": (_i, [C.POINTER(VAECfg), _i, C.POINTER(C.c_char_p), C.POINTER(_vp), C.POINTER(_i64), C.POINTER(_vp)]),
     "ldmseg_vae_destroy": (None, [_vp]),
     "ldmseg_vae_decode": (_i, [_vp, _vp, _f, _i, _i, _i, _vp, _vp]),
+    "ldmseg_vae_decode_argmax": (_i, [_vp, _vp, _f, _i, _i, _f, _i64, _vp, _vp, _vp]),
     "ldmseg_vae_encode": (_i, [_vp, _vp, _f, _f, _i, _i, _vp, _vp]),
     "ldmseg_vae_posterior": (_i, [_vp, _vp, _f, _i, _i, _vp, _vp]),
     "ldmseg_vae_num_params": (_i64, [_vp]),

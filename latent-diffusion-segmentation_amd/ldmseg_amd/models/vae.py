@@ -143,6 +143,21 @@ class GeneralVAESeg(object):
                                                     _lib.stream_ptr(z.device)), "ldmseg_vae_decode")
         return out
 
+    def decode_argmax(self, z: torch.Tensor, z_scale: float = 1.0, mask_th: Optional[float] = None,
+                      ignore_label: int = 0, return_prob: bool = False):
+        """Fused decode -> bilinear x2 -> argmax (+ max-softmax threshold): predictions [B,8L,8L] int64."""
+        z = _lib.require_cuda_f32(z, "z")
+        B, _, L, _ = z.shape
+        up = self._upscale * L * self.interpolation_factor
+        ids = torch.empty((B, up, up), device=z.device, dtype=torch.int64)
+        prob = torch.empty((B, up, up), device=z.device, dtype=torch.float32) if return_prob else None
+        with torch.cuda.device(z.device):
+            _lib.check(_lib.lib().ldmseg_vae_decode_argmax(self._h, _lib.ptr(z), float(z_scale), B, L,
+                                                           -1.0 if mask_th is None else float(mask_th), int(ignore_label),
+                                                           _lib.ptr(ids), _lib.ptr(prob), _lib.stream_ptr(z.device)),
+                       "ldmseg_vae_decode_argmax")
+        return (ids, prob) if return_prob else ids
+
     def forward(self, sample, sample_posterior: bool = True, return_dict: bool = True,
                 generator: Optional[torch.Generator] = None, rgb_sample=None, valid_mask=None):
         if rgb_sample is not None:

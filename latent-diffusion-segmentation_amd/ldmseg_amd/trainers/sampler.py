@@ -205,14 +205,12 @@ class TrainerDiffusion(object):
                        rgb_latents=None, weight_dtype: torch.dtype = torch.float32, mask_th: float = 0.5,
                        ignore_label: int = 0):
         """:397-442.  The 1/scaling_factor multiply is fused into the decoder's input packing."""
-        images = self.vae_semseg.decode(latents, z_scale=1.0 / self.vae_semseg.scaling_factor).float()
+        zs = 1.0 / self.vae_semseg.scaling_factor
         if return_logits:
-            return images
-        predictions = torch.argmax(images, dim=1)
-        if threshold_output:
-            probs = torch.softmax(images, dim=1).max(dim=1)[0]
-            predictions[probs < mask_th] = ignore_label
-        return predictions
+            return self.vae_semseg.decode(latents, z_scale=zs).float()
+        # argmax (+ max-softmax threshold) fused with the decoder tail: the logits are never materialised
+        return self.vae_semseg.decode_argmax(latents, z_scale=zs, mask_th=mask_th if threshold_output else None,
+                                             ignore_label=ignore_label)
 
     @torch.no_grad()
     def encode_inputs(self, images: torch.Tensor, sample_posterior: bool = False, encode_func=None,

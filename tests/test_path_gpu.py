@@ -264,3 +264,30 @@ def test_models_from_reference_style_checkpoint(tmp_path, unet_sd, vae_sd, unets
     x = torch.randn(1, 12, 16, 16, generator=torch.Generator().manual_seed(5)).to(DEV)
     assert torch.equal(u(x, 321).sample, unets["fp32"](x, 321).sample)
     assert list(checkpoint.vae_state_from(data)) == list(vae_sd)
+
+
+# ------------------------------------------------------------------ section 8(f) rank 1: fused decode tail
+def test_decode_argmax_vs_oracle(vae, vae_sd):
+    v, mode = vae
+    g = torch.Generator().manual_seed(33)
+    z = torch.randn(2, 4, 8, 8, generator=g)
+    with torch.no_grad():
+        logits = o_vae.decode(vae_sd, z * 5.0, interpolate=True)
+    ref_ids = logits.argmax(1)
+    sm = torch.softmax(logits, 1)
+    ref_prob = sm.max(1)[0]
+    top2 = logits.topk(2, dim=1)[0]
+    margin = top2[:, 0] - top2[:, 1]
+    ids, prob = v.decode_argmax(z.to(DEV), z_scale=5.0, return_prob=True)
+    assert ids.dtype == torch.int64 and ids.shape == (2, 64, 64)
+    clear = margin > (1e-3 if mode == "fp32" else 5e-2) * logits.abs().max()
+    assert clear.float().mean() > 0.3
+    assert torch.equal(ids.cpu()[clear], ref_ids[clear])                    # argmax wherever it is not a near-tie
+    assert (ids.cpu() == ref_ids).float().mean() > (0.999 if mode == "fp32" else 0.97)
+    assert (prob.cpu() - ref_prob).abs().max() < (1e-3 if mode == "fp32" else 5e-2)
+    th = float(ref_prob.median())
+    ids_t = v.decode_argmax(z.to(DEV), z_scale=5.0, mask_th=th, ignore_label=255)
+    safe = (ref_prob - th).abs() > (1e-3 if mode == "fp32" else 5e-2)
+    expect = torch.where(ref_prob < th, torch.full_like(ref_ids, 255), ref_ids)
+    sel = safe & clear
+    assert torch.equal(ids_t.cpu()[sel], expect[sel])
