@@ -73,10 +73,13 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
 }
 
-// NST = number of LDS stages (full K tiles) in the ring.  In iteration kt every wave issues the DMA
-// of tile kt+NST-1 into the stage that was read in iteration kt-1, computes tile kt, then waits
-// with a COUNTED vmcnt until tile kt+1 has landed (NST-2 later tiles stay in flight) and hits the
-// one barrier of the iteration.
+// Persistent implicit-GEMM.  A fixed grid of workgroups (two per CU) walks the work items
+// (output tile, K slice); NST LDS stages (full K tiles) form a ring and the LDS-DMA stream runs NST-1
+// tiles ahead of the MFMA stream ACROSS item boundaries, so the DMA round trip at the start of an
+// item and the epilogue at its end overlap with neighbouring items instead of idling the CU.
+// Per K tile every wave: issues the DMA of stream position +NST-1 into the stage read one tile ago,
+// computes the current tile, waits with a COUNTED vmcnt until the next tile has landed (later ones
+// stay in flight) and passes the single barrier.
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int NST>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(const IgemmParams p) {
   constexpr int NW = WAVES_M * WAVES_N;   // 4 waves (128-row tiles, 2 workgroups/CU) or 8 (256-row tiles)
@@ -93,27 +96,26 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(const Ige
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
-  // ---- XCD-aware tile assignment (bijective for any grid size) ----
+  // ---- work items: (m tile, n tile, K slice), n fastest.  Round j of this workgroup is item
+  // j*G + b', b' = XCD-aware bijective remap of blockIdx within the grid: every XCD (own L2) works
+  // on a contiguous run of tiles in each round.
   const int NT = p.N / BN;
-  int wg;
+  const int MT = (p.M + BM - 1) / BM;
+  const int ntiles = MT * NT;
+  const int nsplit = p.splits > 1 ? p.splits : 1;
+  const int nwork = ntiles * nsplit;
+  const int G = gridDim.x;
+  int first_item;
   {
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int bid = blockIdx.x;
+    const int q = G >> 3, r = G & 7, xcd = bid & 7, idx = bid >> 3;
+    first_item = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int mt = wg / NT, nt = wg % NT;
-  const int m0 = mt * BM, n0 = nt * BN;
+  if (first_item >= nwork) return;
 
   const int Ctot = p.C0 + p.C1;
   const int K = p.taps * Ctot;
   const int nk_total = K / BKE;
-  int kt_begin = 0, kt_end = nk_total;
-  if (p.splits > 1) {
-    const int z = blockIdx.y;
-    kt_begin = (int)((long)nk_total * z / p.splits);
-    kt_end = (int)((long)nk_total * (z + 1) / p.splits);
-  }
-
   const int Hlog = p.up ? 2 * p.Hi : p.Hi;
   const int Wlog = p.up ? 2 * p.Wi : p.Wi;
   const int pad = (p.taps == 9) ? 1 : 0;
@@ -130,50 +132,63 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(const Ige
   static_assert(BM % (8 * NW) == 0 && BN % 8 == 0, "tile rows / loader mismatch");
   const int ld_r = lane >> 3;                  // row within the 8-row group (== row & 7)
   const int ld_j = (lane & 7) ^ ld_r;          // logical 16-B chunk this lane fetches
-  RowInfo ri[XG];
-#pragma unroll
-  for (int i = 0; i < XG; ++i) {
-    const int m = m0 + (i * NW + wave) * 8 + ld_r;
-    if (m < p.M) {
-      const int b = m / HWo, rem = m - b * HWo;
-      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-      ri[i].pix_base = b * p.Hi * p.Wi;
-      ri[i].iy0 = oy * p.stride - pad;
-      ri[i].ix0 = ox * p.stride - pad;
-    } else {
-      ri[i].pix_base = 0;
-      ri[i].iy0 = -(1 << 28);
-      ri[i].ix0 = 0;
-    }
-  }
-  // W rows: wave-uniform base (advances 128 B per K tile) + per-lane 32-bit offsets
-  const unsigned char* wtile0 = (const unsigned char*)p.W + (size_t)n0 * K * sizeof(T);
-  unsigned woff[WG];
+  const bool w_last = (WREM == 0) || (wave < WREM);   // owns a group in the last W round (wave-uniform)
+  const unsigned char* zpage = (const unsigned char*)p.zeros;
+  const unsigned lds_wave = __builtin_amdgcn_readfirstlane(
+      (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)smem) + (unsigned)wave * 1024u);
+  unsigned woff[WG];                           // per-lane W row offsets relative to the item's W tile
 #pragma unroll
   for (int i = 0; i < WG; ++i)
     woff[i] = (unsigned)(((size_t)((i * NW + wave) * 8 + ld_r) * K) * sizeof(T)) + (unsigned)ld_j * 16u;
-  const bool w_last = (WREM == 0) || (wave < WREM);   // owns a group in the last W round (wave-uniform)
-  const unsigned char* zpage = (const unsigned char*)p.zeros;
-  // wave-uniform LDS byte address of this wave's first group in stage 0
-  const unsigned lds_wave = __builtin_amdgcn_readfirstlane(
-      (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)smem) + (unsigned)wave * 1024u);
 
-  // tap / channel cursor of the tile being fetched
+  auto item_range = [&](int item, int& m0, int& n0, int& z, int& kb, int& ke) __attribute__((always_inline)) {
+    const int tile = item % ntiles;
+    z = item / ntiles;
+    const int mt = tile / NT, nt = tile - mt * NT;
+    m0 = mt * BM;
+    n0 = nt * BN;
+    kb = (int)((long)nk_total * z / nsplit);
+    ke = (int)((long)nk_total * (z + 1) / nsplit);
+  };
+
+  // ================= fetch stream state (runs NST-1 K tiles ahead of the compute stream) =================
+  int f_item = first_item, f_kt = 0, f_kend = 0;   // item / next K tile / end of its slice
+  bool f_done = false;
+  RowInfo ri[XG];
+  const unsigned char* wtile0 = nullptr;
   int f_tap = 0, f_cc = 0;
-  {
-    const int kt = kt_begin;
-    const int tiles_per_tap = Ctot / BKE;
-    f_tap = kt / tiles_per_tap;
-    f_cc = (kt - f_tap * tiles_per_tap) * BKE;
-  }
-
-  // A "segment" is a run of K tiles inside one (tap, source tensor): there the gather address of a
-  // row only advances by 128 B per tile.  Row pointers are set up once per segment; rows whose tap
-  // falls outside the image sit on the zero page with stride 0.
   const unsigned char* rowptr[XG];
   unsigned rowinc[XG];
   bool need_setup = true;
-  auto seg_setup = [&]() {
+
+  auto item_setup = [&]() __attribute__((always_inline)) {
+    int m0, n0, z;
+    item_range(f_item, m0, n0, z, f_kt, f_kend);
+#pragma unroll
+    for (int i = 0; i < XG; ++i) {
+      const int m = m0 + (i * NW + wave) * 8 + ld_r;
+      if (m < p.M) {
+        const int b = m / HWo, rem = m - b * HWo;
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        ri[i].pix_base = b * p.Hi * p.Wi;
+        ri[i].iy0 = oy * p.stride - pad;
+        ri[i].ix0 = ox * p.stride - pad;
+      } else {
+        ri[i].pix_base = 0;
+        ri[i].iy0 = -(1 << 28);
+        ri[i].ix0 = 0;
+      }
+    }
+    wtile0 = (const unsigned char*)p.W + (size_t)n0 * K * sizeof(T);
+    const int tiles_per_tap = Ctot / BKE;
+    f_tap = f_kt / tiles_per_tap;
+    f_cc = (f_kt - f_tap * tiles_per_tap) * BKE;
+    need_setup = true;
+  };
+  // A "segment" is a run of K tiles inside one (tap, source tensor): there the gather address of a
+  // row only advances by 128 B per tile.  Row pointers are set up once per segment; rows whose tap
+  // falls outside the image sit on the zero page with stride 0.
+  auto seg_setup = [&]() __attribute__((always_inline)) {
     const int ky = (p.taps == 9) ? f_tap / 3 : 0;
     const int kx = (p.taps == 9) ? f_tap - ky * 3 : 0;
     const unsigned char* sbase;
@@ -190,36 +205,36 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(const Ige
       rowinc[i] = inb ? (unsigned)kRowBytes : 0u;
     }
   };
-
-  auto fetch = [&](int kt, int stage) {
+  // issue the DMA of the next stream position into `stage`; returns false when the stream is exhausted
+  auto fetch_next = [&](int stage) __attribute__((always_inline)) -> bool {
+    if (f_done) return false;
+    if (f_kt == f_kend) {                      // slice finished: move to this workgroup's next item
+      f_item += G;
+      if (f_item >= nwork) { f_done = true; return false; }
+      item_setup();
+    }
     if (need_setup) seg_setup();
-    const unsigned dst = lds_wave + (unsigned)stage * (unsigned)kStageBytes;
+    // (values below are wave-uniform; readfirstlane makes that provable so they can live in SGPRs)
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_wave + (unsigned)stage * (unsigned)kStageBytes);
 #pragma unroll
     for (int i = 0; i < XG; ++i) {
       glds16(rowptr[i], dst + i * (NW * 1024));
       rowptr[i] += rowinc[i];
     }
-    const unsigned char* wt = wtile0 + (size_t)kt * kRowBytes;
+    const unsigned long long wt_u = (unsigned long long)(uintptr_t)(wtile0 + (size_t)f_kt * kRowBytes);
+    const unsigned wt_lo = __builtin_amdgcn_readfirstlane((unsigned)wt_u);
+    const unsigned wt_hi = __builtin_amdgcn_readfirstlane((unsigned)(wt_u >> 32));
+    const unsigned char* wt = (const unsigned char*)(uintptr_t)(((unsigned long long)wt_hi << 32) | wt_lo);
     const unsigned wdst = dst + BM * kRowBytes;
 #pragma unroll
     for (int i = 0; i < WG; ++i)
       if (i + 1 < WG || w_last) glds16_sbase(woff[i], wt, wdst + i * (NW * 1024));
+    ++f_kt;
     f_cc += BKE;
     if (f_cc == Ctot) { f_cc = 0; ++f_tap; }
     need_setup = (f_cc == 0) | (f_cc == p.C0);
+    return true;
   };
-
-  f32x4 acc[NF][MF];
-#pragma unroll
-  for (int a = 0; a < NF; ++a)
-#pragma unroll
-    for (int b = 0; b < MF; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // fragment read offsets: row = frag*16 + (lane&15); chunk = kg*4 + (lane>>4), XOR (row&7)
-  const int fr_row = (lane & 15) * kRowBytes;
-  const int fr_c0 = (((lane >> 4)) ^ (lane & 7)) * 16;
-  const int fr_c1 = (((lane >> 4) + 4) ^ (lane & 7)) * 16;
-
   // wait until at most AHEAD of this wave's per-tile DMA batches are still in flight
   auto wait_dma = [&](auto ahead_tag) __attribute__((always_inline)) {
     constexpr int AHEAD = decltype(ahead_tag)::value;
@@ -233,58 +248,26 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(const Ige
     }
   };
 
-  // ---- prologue: NST-1 tiles in flight, the first one landed ----
-  const int nkt = kt_end - kt_begin;
+  f32x4 acc[NF][MF];
 #pragma unroll
-  for (int j = 0; j < NST - 1; ++j)
-    if (j < nkt) fetch(kt_begin + j, j);
-  if (nkt >= NST - 1) wait_dma(std::integral_constant<int, NST - 2>{});
-  else wait_dma(std::integral_constant<int, 0>{});
-  __syncthreads();
+  for (int a = 0; a < NF; ++a)
+#pragma unroll
+    for (int b = 0; b < MF; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  int cur = 0;            // stage of tile kt
-  int fst = NST - 1;      // stage the next DMA goes to
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    const bool more = (kt + NST - 1 < kt_end);
-    if (more && !(p.dbg & 1)) fetch(kt + NST - 1, fst);
-    const unsigned char* xs = smem + cur * kStageBytes + (wm * WTM) * kRowBytes + fr_row;
-    const unsigned char* ws = smem + cur * kStageBytes + (BM + wn * WTN) * kRowBytes + fr_row;
-#pragma unroll
-    for (int kg = 0; kg < 2; ++kg) {
-      const int co = kg ? fr_c1 : fr_c0;
-      uint4 wf[NF], xf[MF];
-#pragma unroll
-      for (int a = 0; a < NF; ++a) wf[a] = *(const uint4*)(ws + a * 16 * kRowBytes + co);
-#pragma unroll
-      for (int b = 0; b < MF; ++b) xf[b] = *(const uint4*)(xs + b * 16 * kRowBytes + co);
-      if (!(p.dbg & 4)) {
-#pragma unroll
-        for (int a = 0; a < NF; ++a)
-#pragma unroll
-          for (int b = 0; b < MF; ++b) mma_kgroup<T>(wf[a], xf[b], acc[a][b]);
-      } else {
-#pragma unroll
-        for (int a = 0; a < NF; ++a) asm volatile("" ::"v"(wf[a].x), "v"(wf[a].w));
-#pragma unroll
-        for (int b = 0; b < MF; ++b) asm volatile("" ::"v"(xf[b].x), "v"(xf[b].w));
-      }
-    }
-    // tile kt+1 must have landed before anyone reads it; later tiles may stay in flight
-    if (more) wait_dma(std::integral_constant<int, NST - 2>{});
-    else wait_dma(std::integral_constant<int, 0>{});
-    __syncthreads();
-    cur = (cur + 1 == NST) ? 0 : cur + 1;
-    fst = (fst + 1 == NST) ? 0 : fst + 1;
-  }
-
-  // ---- epilogue: lane holds n = nb + 4*(lane>>4) + r (r=0..3) of m = mb + (lane&15) ----
+  // fragment read offsets: row = frag*16 + (lane&15); chunk = kg*4 + (lane>>4), XOR (row&7)
+  const int fr_row = (lane & 15) * kRowBytes;
+  const int fr_c0 = (((lane >> 4)) ^ (lane & 7)) * 16;
+  const int fr_c1 = (((lane >> 4) + 4) ^ (lane & 7)) * 16;
   const int lg = lane >> 4;
+
+  auto epilogue = [&](int m0, int n0, int zc) __attribute__((always_inline)) {
+  // ---- epilogue: lane holds n = nb + 4*(lane>>4) + r (r=0..3) of m = mb + (lane&15) ----
 #pragma unroll
   for (int b = 0; b < MF; ++b) {
     const int m = m0 + wm * WTM + b * 16 + (lane & 15);
     if (m >= p.M) continue;
     if (p.splits > 1) {
-      float* dst = p.partial + ((size_t)blockIdx.y * p.M + m) * p.N;
+      float* dst = p.partial + ((size_t)zc * p.M + m) * p.N;
 #pragma unroll
       for (int a = 0; a < NF; ++a) {
         const int n = n0 + wn * WTN + a * 16 + lg * 4;
@@ -370,6 +353,61 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(const Ige
       }
     }
   }
+  };
+
+  // ---- prologue: NST-1 stream positions in flight, the first one landed ----
+  item_setup();
+  int issued = 0;
+#pragma unroll
+  for (int j = 0; j < NST - 1; ++j)
+    if (fetch_next(j)) ++issued;
+  if (issued == NST - 1) wait_dma(std::integral_constant<int, NST - 2>{});
+  else wait_dma(std::integral_constant<int, 0>{});
+  __syncthreads();
+
+  int cur = 0;            // stage of the tile being computed
+  int fst = NST - 1;      // stage the next DMA goes to
+  for (int c_item = first_item; c_item < nwork; c_item += G) {
+    int m0c, n0c, zc, kb, ke;
+    item_range(c_item, m0c, n0c, zc, kb, ke);
+    for (int kt = kb; kt < ke; ++kt) {
+      const bool more = (p.dbg & 1) ? false : fetch_next(fst);
+      const unsigned char* xs = smem + cur * kStageBytes + (wm * WTM) * kRowBytes + fr_row;
+      const unsigned char* ws = smem + cur * kStageBytes + (BM + wn * WTN) * kRowBytes + fr_row;
+#pragma unroll
+      for (int kg = 0; kg < 2; ++kg) {
+        const int co = kg ? fr_c1 : fr_c0;
+        uint4 wf[NF], xf[MF];
+#pragma unroll
+        for (int a = 0; a < NF; ++a) wf[a] = *(const uint4*)(ws + a * 16 * kRowBytes + co);
+#pragma unroll
+        for (int b = 0; b < MF; ++b) xf[b] = *(const uint4*)(xs + b * 16 * kRowBytes + co);
+        if (!(p.dbg & 4)) {
+#pragma unroll
+          for (int a = 0; a < NF; ++a)
+#pragma unroll
+            for (int b = 0; b < MF; ++b) mma_kgroup<T>(wf[a], xf[b], acc[a][b]);
+        } else {
+#pragma unroll
+          for (int a = 0; a < NF; ++a) asm volatile("" ::"v"(wf[a].x), "v"(wf[a].w));
+#pragma unroll
+          for (int b = 0; b < MF; ++b) asm volatile("" ::"v"(xf[b].x), "v"(xf[b].w));
+        }
+      }
+      // the next stream position must have landed before anyone reads it; later ones may stay in flight
+      if (more) wait_dma(std::integral_constant<int, NST - 2>{});
+      else wait_dma(std::integral_constant<int, 0>{});
+      __syncthreads();
+      cur = (cur + 1 == NST) ? 0 : cur + 1;
+      fst = (fst + 1 == NST) ? 0 : fst + 1;
+    }
+    // the DMA of the next item's first tiles is already in flight while this epilogue runs
+    epilogue(m0c, n0c, zc);
+#pragma unroll
+    for (int a = 0; a < NF; ++a)
+#pragma unroll
+      for (int b = 0; b < MF; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 }
 
 // split-K finish: out = sum_z partial[z] + bias (+rowbias)(+resid), optional SiLU  (EPI_STORE only)
@@ -398,6 +436,17 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const IgemmParams p)
   }
 }
 
+int num_cus() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
 const void* zero_page() {
   static void* z = nullptr;
   if (!z) {
@@ -418,6 +467,11 @@ int run(const IgemmParams& pin, hipStream_t s) {
   p.zeros = zero_page();
   if (!p.zeros) return -3;
   const int mt = (p.M + BM - 1) / BM, nt = p.N / BN;
+  const int nwork = mt * nt * (p.splits > 1 ? p.splits : 1);
+  // persistent grid: as many workgroups as fit on the chip at once (2 per CU for the 4-wave tiles,
+  // 1 per CU for the 8-wave ones); each walks nwork / grid items
+  int resident = num_cus() * ((WM * WN == 4 && NST == 2) ? 2 : 1);
+  const int grid_x = nwork < resident ? nwork : resident;
   const size_t lds = (size_t)NST * (BM + BN) * kRowBytes;
   auto kern = igemm_kernel<T, BM, BN, WM, WN, NST>;
   static bool attr_set = false;
@@ -425,8 +479,7 @@ int run(const IgemmParams& pin, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  dim3 grid(mt * nt, p.splits > 1 ? p.splits : 1);
-  hipLaunchKernelGGL(kern, grid, dim3(WM * WN * 64), lds, s, p);
+  hipLaunchKernelGGL(kern, dim3(grid_x), dim3(WM * WN * 64), lds, s, p);
   if (p.splits > 1) {
     const size_t total = (size_t)p.M * (p.n_valid >> 2);
     int blocks = (int)((total + 255) / 256);
