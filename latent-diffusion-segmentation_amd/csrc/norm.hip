@@ -233,6 +233,68 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* x, T* y, const 
   }
 }
 
+// Small feature maps (8x8 .. 32x32): one workgroup per (image, group) keeps the whole group in
+// registers - statistics, normalisation and the store in ONE launch instead of two dependent ones
+// (these tensors are a few hundred KB; the two-kernel path is pure launch latency there).
+// Elements are handled in 4-byte units U (2 bf16 / 1 f32); cpg is even so a group starts unit-aligned.
+template <typename T, int MAXU>
+__global__ __launch_bounds__(256) void gn_small_kernel(const GNParams p) {
+  constexpr int EPU = 4 / (int)sizeof(T);          // elements per unit
+  const int C = p.C0 + p.C1;
+  const int cpg = C / p.groups;
+  const int upg = cpg / EPU;                        // units per pixel of this group
+  const int g = blockIdx.x, b = blockIdx.y;
+  const int nunits = p.HW * upg;
+  const int c_first = g * cpg;
+  float v[MAXU][EPU];
+  float s = 0.f, q = 0.f;
+#pragma unroll
+  for (int k = 0; k < MAXU; ++k) {
+    const int u = threadIdx.x + k * 256;
+    if (u < nunits) {
+      const int pix = u / upg, j = u - pix * upg;
+      const int c = c_first + j * EPU;
+      const T* src = (c < p.C0) ? (const T*)p.src0 + ((size_t)b * p.HW + pix) * p.C0 + c
+                                : (const T*)p.src1 + ((size_t)b * p.HW + pix) * p.C1 + (c - p.C0);
+      const uint32_t raw = *(const uint32_t*)src;
+      if constexpr (EPU == 2) { v[k][0] = bits_f32(raw << 16); v[k][1] = bits_f32(raw & 0xffff0000u); }
+      else { v[k][0] = bits_f32(raw); }
+#pragma unroll
+      for (int e = 0; e < EPU; ++e) { s += v[k][e]; q += v[k][e] * v[k][e]; }
+    }
+  }
+  __shared__ float red[2][4];
+  s = wave64_sum(s);
+  q = wave64_sum(q);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = q; }
+  __syncthreads();
+  const double st = (double)red[0][0] + (double)red[0][1] + (double)red[0][2] + (double)red[0][3];
+  const double qt = (double)red[1][0] + (double)red[1][1] + (double)red[1][2] + (double)red[1][3];
+  const double n = (double)p.HW * cpg;
+  const double mean_d = st / n;
+  double var = qt / n - mean_d * mean_d;
+  if (var < 0.0) var = 0.0;
+  const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(var + (double)p.eps));
+#pragma unroll
+  for (int k = 0; k < MAXU; ++k) {
+    const int u = threadIdx.x + k * 256;
+    if (u < nunits) {
+      const int pix = u / upg, j = u - pix * upg;
+      const int c = c_first + j * EPU;
+      float y[EPU];
+#pragma unroll
+      for (int e = 0; e < EPU; ++e) {
+        const float a = rstd * p.gamma[c + e];
+        y[e] = v[k][e] * a + (p.beta[c + e] - mean * a);
+        if (p.silu) y[e] = silu_f(y[e]);
+      }
+      T* dst = (T*)p.out + ((size_t)b * p.HW + pix) * C + c;
+      if constexpr (EPU == 2) *(uint32_t*)dst = pack_bf16x2(y[0], y[1]);
+      else *(float*)dst = y[0];
+    }
+  }
+}
+
 template <typename T>
 int run_gn(const GNParams& p, hipStream_t s) {
   constexpr int PC = Chunk<T>::N;
@@ -240,6 +302,16 @@ int run_gn(const GNParams& p, hipStream_t s) {
   if (C % p.groups != 0 || C % PC != 0 || p.C0 % PC != 0 || p.groups > 64) return -2;
   if (C / p.groups < PC) return -2;               // a 16-B vector may span at most two groups
   if (C / PC > 256 * kMaxIter) return -2;
+  {
+    constexpr int EPU = 4 / (int)sizeof(T);
+    const int cpg = C / p.groups;
+    const long nunits = (long)p.HW * (cpg / EPU);
+    // measured: wins for the 8x8 maps (16 -> 9 us), loses from 16x16 up (its 4-byte strided loads)
+    if (cpg % EPU == 0 && p.C0 % EPU == 0 && nunits <= 256 * 12 && (long)p.B * p.groups >= 128) {
+      hipLaunchKernelGGL((gn_small_kernel<T, 12>), dim3(p.groups, p.B), dim3(256), 0, s, p);
+      return hipGetLastError() == hipSuccess ? 0 : -3;
+    }
+  }
   hipLaunchKernelGGL(gn_partial_kernel<T>, dim3(p.nchunk, p.B), dim3(256), 0, s, p);
   // pixel chunks: >= 4 pixels per thread row, ~2048 workgroups in total
   const int nvec = C / PC;
