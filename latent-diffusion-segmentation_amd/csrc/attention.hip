@@ -325,10 +325,12 @@ int run(const void* qkv, void* out, int B, int N, int C, int heads, hipStream_t 
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
+int g_attn_qf1 = 0;
+
 template <typename T>
 int dispatch(const void* qkv, void* out, int B, int N, int C, int heads, hipStream_t s) {
   const int d = C / heads;
-  const bool big = N >= 256;
+  const bool big = N >= 256 && !g_attn_qf1;
   switch (d) {
     case 40: return big ? run<T, 40, 2>(qkv, out, B, N, C, heads, s) : run<T, 40, 1>(qkv, out, B, N, C, heads, s);
     case 80: return big ? run<T, 80, 2>(qkv, out, B, N, C, heads, s) : run<T, 80, 1>(qkv, out, B, N, C, heads, s);
@@ -338,6 +340,8 @@ int dispatch(const void* qkv, void* out, int B, int N, int C, int heads, hipStre
 }
 
 }  // namespace
+
+void attention_set_qf1(int v) { g_attn_qf1 = v; }
 
 int launch_attention(const void* qkv, void* out, int B, int N, int C, int heads, int dtype, hipStream_t s) {
   if (C % heads != 0 || N <= 0) return -2;

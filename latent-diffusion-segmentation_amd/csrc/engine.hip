@@ -261,11 +261,13 @@ struct Exec {
         p.partial = (float*)ws->scratch((size_t)sp * p.M * p.N * sizeof(float));
       }
     }
-    const double flops = 2.0 * p.M * (double)p.n_valid * p.taps * (p.C0 + p.C1);
+    // GEGLU: n_valid counts the OUTPUT channels, the GEMM computes value and gate columns for each
+    const double ncols = (p.epi == EPI_GEGLU) ? 2.0 * p.n_valid : (double)p.n_valid;
+    const double flops = 2.0 * p.M * ncols * p.taps * (p.C0 + p.C1);
     const double bytes = ((double)p.M * (p.C0 + p.C1) + (double)p.N * p.taps * (p.C0 + p.C1) + (double)p.M * p.n_valid) * esize(dt);
     std::string label;
     if (g_prof.on && !dry())
-      label = "M=" + std::to_string(p.M) + " N=" + std::to_string(p.n_valid) + " K=" + std::to_string(p.taps * (p.C0 + p.C1)) +
+      label = "M=" + std::to_string(p.M) + " N=" + std::to_string((int)ncols) + " K=" + std::to_string(p.taps * (p.C0 + p.C1)) +
               " taps=" + std::to_string(p.taps) + " stride=" + std::to_string(p.stride) + " up=" + std::to_string(p.up) +
               " epi=" + std::to_string(p.epi) + " splits=" + std::to_string(p.splits);
     ProfScope ps(0, s, flops, bytes, dry(), label);
@@ -1129,6 +1131,7 @@ int ldmseg_profile_read(int family, int64_t* launches, double* total_ms, double*
 // tuning knobs for experiments: key 0 = igemm K-loop ring depth (2, 3, 4)
 int ldmseg_debug_set(int key, int value) {
   if (key == 0) { igemm_set_nbuf(value); return 0; }
+  if (key == 2) { attention_set_qf1(value); return 0; }
   if (key == 1) { igemm_set_dbg(value); return 0; }   // bits 0-7 ablation flags, bits 8-9 tile policy
   return fail(LDMSEG_E_ARG, "unknown debug key");
 }

@@ -81,7 +81,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // computes the current tile, waits with a COUNTED vmcnt until the next tile has landed (later ones
 // stay in flight) and passes the single barrier.
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int NST>
-__global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(const IgemmParams p) {
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(const IgemmParams p) {   // <=256 regs: 2 workgroups/CU
   constexpr int NW = WAVES_M * WAVES_N;   // 4 waves (128-row tiles, 2 workgroups/CU) or 8 (256-row tiles)
   static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
   constexpr int BKE = kRowBytes / (int)sizeof(T);  // K elements per tile
@@ -260,8 +260,87 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(const Ige
   const int fr_c1 = (((lane >> 4) + 4) ^ (lane & 7)) * 16;
   const int lg = lane >> 4;
 
+  // Row-major epilogue for the plain store (EPI_STORE): the MFMA layout gives a lane 4 channels of one
+  // row, i.e. 8-byte stores in 32-byte runs - measured 1.4 TB/s and most of a short-K GEMM's time.
+  // Instead each wave parks a 16-row x WTN block (fp32, after bias) in the LDS stage that is free at
+  // the end of an item (the one the next DMA will target), then every lane takes 16 output bytes of
+  // one row: 16-byte residual loads and 16-byte stores covering whole rows of the wave's tile.
+  auto epilogue_rows = [&](int m0, int n0, int stage_free) __attribute__((always_inline)) {
+    constexpr int E = 16 / (int)sizeof(T);              // output elements per 16-byte chunk
+    constexpr int SROW = WTN * 4 + 16;                  // staged row stride (bytes), padded
+    constexpr int CPR = WTN / E;                        // chunks per row
+    constexpr int NCH = 16 * CPR;                       // chunks per 16-row block
+    unsigned char* stg = smem + stage_free * kStageBytes + wave * (16 * SROW);
+    const int lq = lane & 15;
+    // bias of this lane's NF channel quads: loaded ONCE per item, unconditionally and back to back
+    // (a load per fragment behind its own branch costs one exposed L2 round trip each)
+    const float* biasp = p.bias ? p.bias : (const float*)p.zeros;
+    const int nl = n0 + wn * WTN + lg * 4;
+    f32x4 bv[NF];
+#pragma unroll
+    for (int a = 0; a < NF; ++a) bv[a] = *(const f32x4*)(biasp + nl + a * 16);
+#pragma unroll
+    for (int b = 0; b < MF; ++b) {
+      const int mb = m0 + wm * WTM + b * 16;
+      {
+        const int m = mb + lq;
+        const int bimg = (m < p.M ? m : p.M - 1) / HWo;
+        if (p.rowbias) {                                   // time-embedding row of this pixel's image
+          const float* rbp = p.rowbias + (size_t)bimg * p.rb_stride + nl;
+          f32x4 rb[NF];
+#pragma unroll
+          for (int a = 0; a < NF; ++a) rb[a] = *(const f32x4*)(rbp + a * 16);
+#pragma unroll
+          for (int a = 0; a < NF; ++a)
+            *(f32x4*)(stg + lq * SROW + (a * 16 + lg * 4) * 4) = acc[a][b] + bv[a] + rb[a];
+        } else {
+#pragma unroll
+          for (int a = 0; a < NF; ++a)
+            *(f32x4*)(stg + lq * SROW + (a * 16 + lg * 4) * 4) = acc[a][b] + bv[a];
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's block is in LDS (per-wave region)
+#pragma unroll
+      for (int i = 0; i < (NCH + 63) / 64; ++i) {
+        const int c = lane + i * 64;
+        if (c < NCH) {
+          const int row = c / CPR, cc = c - row * CPR;
+          const int m = mb + row;
+          const int n = n0 + wn * WTN + cc * E;
+          if (m < p.M && n < p.n_valid) {
+            float v[E];
+            const unsigned char* sp = stg + row * SROW + cc * E * 4;
+#pragma unroll
+            for (int q = 0; q < E / 4; ++q) {
+              const f32x4 t = *(const f32x4*)(sp + q * 16);
+              v[q * 4 + 0] = t[0]; v[q * 4 + 1] = t[1]; v[q * 4 + 2] = t[2]; v[q * 4 + 3] = t[3];
+            }
+            if (p.resid && !(p.dbg & 128)) {
+              float r[E];
+              Chunk<T>::unpack(*(const uint4*)((const T*)p.resid + (size_t)m * p.ldr + n), r);
+#pragma unroll
+              for (int e = 0; e < E; ++e) v[e] += r[e];
+            }
+            if (p.silu) {
+#pragma unroll
+              for (int e = 0; e < E; ++e) v[e] = silu_f(v[e]);
+            }
+            if (!(p.dbg & 64)) *(uint4*)((T*)p.out + (size_t)m * p.ldo + n) = Chunk<T>::pack(v);
+            else asm volatile("" ::"v"(v[0]), "v"(v[E - 1]));
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next block overwrites
+    }
+  };
+
   auto epilogue = [&](int m0, int n0, int zc) __attribute__((always_inline)) {
-  // ---- epilogue: lane holds n = nb + 4*(lane>>4) + r (r=0..3) of m = mb + (lane&15) ----
+  f32x4 gbias[NF];   // GEGLU: bias of the lane's value / gate quads, loaded once per item
+  if (p.epi == EPI_GEGLU) {
+    const float* biasp = p.bias ? p.bias : (const float*)p.zeros;
+#pragma unroll
+    for (int a = 0; a < NF; ++a) gbias[a] = *(const f32x4*)(biasp + n0 + wn * WTN + a * 16 + lg * 4);
+  }
 #pragma unroll
   for (int b = 0; b < MF; ++b) {
     const int m = m0 + wm * WTM + b * 16 + (lane & 15);
@@ -285,8 +364,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(const Ige
           float v[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float av = acc[a][b][r] + p.bias[n + r];
-            const float gv = acc[a + 1][b][r] + p.bias[n + 16 + r];
+            const float av = acc[a][b][r] + gbias[a][r];
+            const float gv = acc[a + 1][b][r] + gbias[a + 1][r];
             v[r] = av * gelu_erf_f(gv);
           }
           T* o = (T*)p.out + (size_t)m * p.ldo + oc;
@@ -318,9 +397,16 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(const Ige
       }
       if (p.epi == EPI_STORE) {
         if (p.resid) {
+          // 4 consecutive channels of one row: a single 8-/16-byte load
           const T* rp = (const T*)p.resid + (size_t)m * p.ldr + n;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += to_f32<T>(rp[r]);
+          if constexpr (sizeof(T) == 2) {
+            const uint2 rr = *(const uint2*)rp;
+            v[0] += bits_f32(rr.x << 16); v[1] += bits_f32(rr.x & 0xffff0000u);
+            v[2] += bits_f32(rr.y << 16); v[3] += bits_f32(rr.y & 0xffff0000u);
+          } else {
+            const f32x4 rr = *(const f32x4*)rp;
+            v[0] += rr[0]; v[1] += rr[1]; v[2] += rr[2]; v[3] += rr[3];
+          }
         }
         if (p.silu) {
 #pragma unroll
@@ -376,6 +462,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(const Ige
       const unsigned char* ws = smem + cur * kStageBytes + (BM + wn * WTN) * kRowBytes + fr_row;
 #pragma unroll
       for (int kg = 0; kg < 2; ++kg) {
+        if (p.dbg & 8) break;          // ablation: no LDS reads, no MFMA
         const int co = kg ? fr_c1 : fr_c0;
         uint4 wf[NF], xf[MF];
 #pragma unroll
@@ -402,7 +489,14 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void igemm_kernel(const Ige
       fst = (fst + 1 == NST) ? 0 : fst + 1;
     }
     // the DMA of the next item's first tiles is already in flight while this epilogue runs
-    epilogue(m0c, n0c, zc);
+    if (!(p.dbg & 16)) {
+      constexpr int E = 16 / (int)sizeof(T);
+      const bool rows_ok = p.epi == EPI_STORE && p.splits <= 1 && !(p.dbg & 32) && (p.n_valid % E == 0) &&
+                           (p.ldo % E == 0) && (!p.resid || p.ldr % E == 0);
+      if (rows_ok) epilogue_rows(m0c, n0c, fst);
+      else epilogue(m0c, n0c, zc);
+    }
+    __syncthreads();   // the staging stage is handed back to the DMA ring
 #pragma unroll
     for (int a = 0; a < NF; ++a)
 #pragma unroll
@@ -450,8 +544,8 @@ int num_cus() {
 const void* zero_page() {
   static void* z = nullptr;
   if (!z) {
-    if (hipMalloc(&z, 256) != hipSuccess) return nullptr;
-    (void)hipMemset(z, 0, 256);
+    if (hipMalloc(&z, 64 << 10) != hipSuccess) return nullptr;     // also serves as an all-zero bias vector
+    (void)hipMemset(z, 0, 64 << 10);
   }
   return z;
 }
