@@ -80,7 +80,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // Per K tile every wave: issues the DMA of stream position +NST-1 into the stage read one tile ago,
 // computes the current tile, waits with a COUNTED vmcnt until the next tile has landed (later ones
 // stay in flight) and passes the single barrier.
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int NST>
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int NST, bool PIPE>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(const IgemmParams p) {   // <=256 regs: 2 workgroups/CU
   constexpr int NW = WAVES_M * WAVES_N;   // 4 waves (128-row tiles, 2 workgroups/CU) or 8 (256-row tiles)
   static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(const 
     const unsigned wdst = dst + BM * kRowBytes;
 #pragma unroll
     for (int i = 0; i < WG; ++i)
-      if (i + 1 < WG || w_last) glds16_sbase(woff[i], wt, wdst + i * (NW * 1024));
+      if ((i + 1 < WG || w_last) && !(p.dbg & 2)) glds16_sbase(woff[i], wt, wdst + i * (NW * 1024));
     ++f_kt;
     f_cc += BKE;
     if (f_cc == Ctot) { f_cc = 0; ++f_tap; }
@@ -331,6 +331,61 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(const 
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next block overwrites
+    }
+  };
+
+  // GEGLU through the same staging: value (fragment a) and gate (a+1) columns of 16 output channels sit in
+  // the same lane (16-row interleaved weight packing), so the product is formed in registers, parked
+  // as a 16-row x WTN/2 fp32 block and leaves as whole 16-byte chunks of output rows.
+  auto epilogue_geglu_rows = [&](int m0, int n0, int stage_free) __attribute__((always_inline)) {
+    if constexpr (NF % 2 == 0) {
+      constexpr int E = 16 / (int)sizeof(T);
+      constexpr int WO = WTN / 2;                       // output channels of the wave's block
+      constexpr int SROW = WO * 4 + 16;
+      constexpr int CPR = WO / E;
+      constexpr int NCH = 16 * CPR;
+      static_assert(WO % E == 0, "GEGLU block / chunk mismatch");
+      unsigned char* stg = smem + stage_free * kStageBytes + wave * (16 * SROW);
+      const int lq = lane & 15;
+      const float* biasp = p.bias ? p.bias : (const float*)p.zeros;
+      const int nl = n0 + wn * WTN + lg * 4;
+      f32x4 bv[NF];
+#pragma unroll
+      for (int a = 0; a < NF; ++a) bv[a] = *(const f32x4*)(biasp + nl + a * 16);
+      const int oc0 = (n0 + wn * WTN) >> 1;
+#pragma unroll
+      for (int b = 0; b < MF; ++b) {
+        const int mb = m0 + wm * WTM + b * 16;
+#pragma unroll
+        for (int a = 0; a < NF; a += 2) {
+          const f32x4 av = acc[a][b] + bv[a];
+          const f32x4 gv = acc[a + 1][b] + bv[a + 1];
+          f32x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = av[r] * gelu_erf_f(gv[r]);
+          *(f32x4*)(stg + lq * SROW + ((a >> 1) * 16 + lg * 4) * 4) = o;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < (NCH + 63) / 64; ++i) {
+          const int c = lane + i * 64;
+          if (c < NCH) {
+            const int row = c / CPR, cc = c - row * CPR;
+            const int m = mb + row;
+            if (m < p.M) {
+              float v[E];
+              const unsigned char* sp = stg + row * SROW + cc * E * 4;
+#pragma unroll
+              for (int q = 0; q < E / 4; ++q) {
+                const f32x4 t = *(const f32x4*)(sp + q * 16);
+                v[q * 4 + 0] = t[0]; v[q * 4 + 1] = t[1]; v[q * 4 + 2] = t[2]; v[q * 4 + 3] = t[3];
+              }
+              *(uint4*)((T*)p.out + (size_t)m * p.ldo + oc0 + cc * E) = Chunk<T>::pack(v);
+            }
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
     }
   };
 
@@ -456,6 +511,51 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(const 
   for (int c_item = first_item; c_item < nwork; c_item += G) {
     int m0c, n0c, zc, kb, ke;
     item_range(c_item, m0c, n0c, zc, kb, ke);
+    if constexpr (PIPE) {
+      // One workgroup per CU (8-wave tiles): nobody else hides this wave's ds_read latency, so the two
+      // 16-byte K groups of a tile live in two fragment sets (A: chunks 0-3, B: 4-7) and the loop is
+      // rotated - every LDS read batch is issued one MFMA batch ahead of its use:
+      //   read B(t) | MFMA A(t) | wait B, DMA(t+1) landed, barrier | read A(t+1) | MFMA B(t)
+      // (with two workgroups per CU the co-resident one fills those gaps and this form measured slower)
+      uint4 wfA[NF], xfA[MF], wfB[NF], xfB[MF];
+#define IGEMM_READ(WF, XF, STAGE, CO)                                                                  \
+  {                                                                                                    \
+    const unsigned char* xs_ = smem + (STAGE) * kStageBytes + (wm * WTM) * kRowBytes + fr_row + (CO);  \
+    const unsigned char* ws_ = smem + (STAGE) * kStageBytes + (BM + wn * WTN) * kRowBytes + fr_row + (CO); \
+    _Pragma("unroll") for (int a = 0; a < NF; ++a) WF[a] = *(const uint4*)(ws_ + a * 16 * kRowBytes);   \
+    _Pragma("unroll") for (int b = 0; b < MF; ++b) XF[b] = *(const uint4*)(xs_ + b * 16 * kRowBytes);   \
+  }
+#define IGEMM_MMA(WF, XF)                                                                              \
+  if (!(p.dbg & 4)) {                                                                                  \
+    _Pragma("unroll") for (int a = 0; a < NF; ++a)                                                      \
+      _Pragma("unroll") for (int b = 0; b < MF; ++b) mma_kgroup<T>(WF[a], XF[b], acc[a][b]);            \
+  } else {                                                                                             \
+    _Pragma("unroll") for (int a = 0; a < NF; ++a) asm volatile("" ::"v"(WF[a].x), "v"(WF[a].w));       \
+    _Pragma("unroll") for (int b = 0; b < MF; ++b) asm volatile("" ::"v"(XF[b].x), "v"(XF[b].w));       \
+  }
+      IGEMM_READ(wfA, xfA, cur, fr_c0)
+      for (int kt = kb; kt < ke; ++kt) {
+        const bool more = (p.dbg & 1) ? false : fetch_next(fst);
+        IGEMM_READ(wfB, xfB, cur, fr_c1)
+        __builtin_amdgcn_sched_barrier(0);
+        IGEMM_MMA(wfA, xfA)
+        __builtin_amdgcn_sched_barrier(0);
+        // B is in registers, so nobody still reads this stage; the next stream position must have
+        // landed before anyone reads it (later ones may stay in flight)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (more) wait_dma(std::integral_constant<int, NST - 2>{});
+        else wait_dma(std::integral_constant<int, 0>{});
+        __syncthreads();
+        cur = (cur + 1 == NST) ? 0 : cur + 1;
+        fst = (fst + 1 == NST) ? 0 : fst + 1;
+        if (kt + 1 < ke) IGEMM_READ(wfA, xfA, cur, fr_c0)   // (an item's first A read follows its predecessor's epilogue)
+        __builtin_amdgcn_sched_barrier(0);
+        IGEMM_MMA(wfB, xfB)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#undef IGEMM_READ
+#undef IGEMM_MMA
+    } else {
     for (int kt = kb; kt < ke; ++kt) {
       const bool more = (p.dbg & 1) ? false : fetch_next(fst);
       const unsigned char* xs = smem + cur * kStageBytes + (wm * WTM) * kRowBytes + fr_row;
@@ -488,12 +588,15 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(const 
       cur = (cur + 1 == NST) ? 0 : cur + 1;
       fst = (fst + 1 == NST) ? 0 : fst + 1;
     }
+    }
     // the DMA of the next item's first tiles is already in flight while this epilogue runs
     if (!(p.dbg & 16)) {
       constexpr int E = 16 / (int)sizeof(T);
       const bool rows_ok = p.epi == EPI_STORE && p.splits <= 1 && !(p.dbg & 32) && (p.n_valid % E == 0) &&
                            (p.ldo % E == 0) && (!p.resid || p.ldr % E == 0);
+      const bool geglu_ok = p.epi == EPI_GEGLU && (NF % 2 == 0) && !(p.dbg & 32) && (p.ldo % E == 0);
       if (rows_ok) epilogue_rows(m0c, n0c, fst);
+      else if (geglu_ok) epilogue_geglu_rows(m0c, n0c, fst);
       else epilogue(m0c, n0c, zc);
     }
     __syncthreads();   // the staging stage is handed back to the DMA ring
@@ -551,10 +654,10 @@ const void* zero_page() {
 }
 
 int g_dbg = 0;       // ablation flags (profiling experiments only)
-int g_big = 1;       // bit0: 8-wave 256-row tiles with a 3-stage ring (-0.15 ms per forward, on);
+int g_big = 13;      // bit0: 8-wave 256-row tiles with a 3-stage ring (-0.15 ms per forward, on);
                      // bit1: 4-stage ring, one workgroup per CU, for mid-size grids (+0.5 ms, off)
 
-template <typename T, int BM, int BN, int WM, int WN, int NST = 2>
+template <typename T, int BM, int BN, int WM, int WN, int NST = 2, bool PIPE = false>
 int run(const IgemmParams& pin, hipStream_t s) {
   IgemmParams p = pin;
   p.dbg = g_dbg;
@@ -567,7 +670,7 @@ int run(const IgemmParams& pin, hipStream_t s) {
   int resident = num_cus() * ((WM * WN == 4 && NST == 2) ? 2 : 1);
   const int grid_x = nwork < resident ? nwork : resident;
   const size_t lds = (size_t)NST * (BM + BN) * kRowBytes;
-  auto kern = igemm_kernel<T, BM, BN, WM, WN, NST>;
+  auto kern = igemm_kernel<T, BM, BN, WM, WN, NST, PIPE>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -598,12 +701,18 @@ int dispatch(const IgemmParams& p, hipStream_t s) {
   const bool big = (g_big & 1) && t256 >= 240;
   // 128-row tiles that cannot put two workgroups on every CU: deeper ring, one workgroup per CU
   const bool deep = (g_big & 2) && !big && t128 >= 200 && t128 < 400;
+  // at most one workgroup per CU anyway: the DMA round trip (~1.1 us) is then hidden only by the
+  // workgroup's own ring, so run it four stages deep instead of two
+  const long t64 = (long)((p.M + 63) / 64) * (p.N / bn) * (p.splits > 1 ? p.splits : 1);
+  const bool lone = (g_big & 4) && small && !big && !deep && t64 <= num_cus();
   switch (bn) {
     case 160:
-      return big ? run<T, 256, 160, 4, 2, 3>(p, s) : deep ? run<T, 128, 160, 2, 2, 4>(p, s)
+      return big ? ((g_big & 8) ? run<T, 256, 160, 4, 2, 3, true>(p, s) : run<T, 256, 160, 4, 2, 3, false>(p, s)) : deep ? run<T, 128, 160, 2, 2, 4>(p, s)
+                 : lone ? run<T, 64, 160, 2, 2, 4>(p, s)
                  : small ? run<T, 64, 160, 2, 2>(p, s) : run<T, 128, 160, 2, 2>(p, s);
     case 128:
-      return big ? run<T, 256, 128, 4, 2, 3>(p, s) : deep ? run<T, 128, 128, 2, 2, 4>(p, s)
+      return big ? ((g_big & 8) ? run<T, 256, 128, 4, 2, 3, true>(p, s) : run<T, 256, 128, 4, 2, 3, false>(p, s)) : deep ? run<T, 128, 128, 2, 2, 4>(p, s)
+                 : lone ? run<T, 64, 128, 2, 2, 4>(p, s)
                  : small ? run<T, 64, 128, 2, 2>(p, s) : run<T, 128, 128, 2, 2>(p, s);
     case 64: return run<T, 128, 64, 4, 1>(p, s);
     default: return run<T, 128, 32, 4, 1>(p, s);
@@ -613,7 +722,7 @@ int dispatch(const IgemmParams& p, hipStream_t s) {
 }  // namespace
 
 void igemm_set_nbuf(int) {}
-void igemm_set_dbg(int f) { g_dbg = f & 0xff; g_big = (f >> 8) & 3; }   // bits 8-9 select the tile policy
+void igemm_set_dbg(int f) { g_dbg = f & 0xff; g_big = (f >> 8) & 15; }   // bits 8-11 select the tile policy
 
 int igemm_pick_bn(int n_real, int epi) {
   if (epi == EPI_GEGLU) return 128;
