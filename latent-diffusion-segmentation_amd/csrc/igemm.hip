@@ -73,6 +73,14 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
 }
 
+// Bytes of the row-major epilogue staging area (one 16-row x WTN fp32 block per wave).  It normally
+// borrows the ring stage that is free at the end of an item; a tile whose stage is smaller than
+// that gets a dedicated area behind the ring.
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+constexpr int epi_stage_bytes() { return WAVES_M * WAVES_N * 16 * ((BN / WAVES_N) * 4 + 16); }
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+constexpr bool epi_stage_dedicated() { return epi_stage_bytes<BM, BN, WAVES_M, WAVES_N>() > (BM + BN) * kRowBytes; }
+
 // Persistent implicit-GEMM.  A fixed grid of workgroups (two per CU) walks the work items
 // (output tile, K slice); NST LDS stages (full K tiles) form a ring and the LDS-DMA stream runs NST-1
 // tiles ahead of the MFMA stream ACROSS item boundaries, so the DMA round trip at the start of an
@@ -270,7 +278,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(const 
     constexpr int SROW = WTN * 4 + 16;                  // staged row stride (bytes), padded
     constexpr int CPR = WTN / E;                        // chunks per row
     constexpr int NCH = 16 * CPR;                       // chunks per 16-row block
-    unsigned char* stg = smem + stage_free * kStageBytes + wave * (16 * SROW);
+    unsigned char* stg = (epi_stage_dedicated<BM, BN, WAVES_M, WAVES_N>() ? smem + NST * kStageBytes
+                                                                          : smem + stage_free * kStageBytes) +
+                         wave * (16 * SROW);
     const int lq = lane & 15;
     // bias of this lane's NF channel quads: loaded ONCE per item, unconditionally and back to back
     // (a load per fragment behind its own branch costs one exposed L2 round trip each)
@@ -345,7 +355,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(const 
       constexpr int CPR = WO / E;
       constexpr int NCH = 16 * CPR;
       static_assert(WO % E == 0, "GEGLU block / chunk mismatch");
-      unsigned char* stg = smem + stage_free * kStageBytes + wave * (16 * SROW);
+      unsigned char* stg = (epi_stage_dedicated<BM, BN, WAVES_M, WAVES_N>() ? smem + NST * kStageBytes
+                                                                            : smem + stage_free * kStageBytes) +
+                           wave * (16 * SROW);
       const int lq = lane & 15;
       const float* biasp = p.bias ? p.bias : (const float*)p.zeros;
       const int nl = n0 + wn * WTN + lg * 4;
@@ -654,7 +666,7 @@ const void* zero_page() {
 }
 
 int g_dbg = 0;       // ablation flags (profiling experiments only)
-int g_big = 13;      // bit0: 8-wave 256-row tiles with a 3-stage ring (-0.15 ms per forward, on);
+int g_big = 29;      // bit0: 8-wave 256-row tiles with a 3-stage ring (-0.15 ms per forward, on);
                      // bit1: 4-stage ring, one workgroup per CU, for mid-size grids (+0.5 ms, off)
 
 template <typename T, int BM, int BN, int WM, int WN, int NST = 2, bool PIPE = false>
@@ -669,7 +681,8 @@ int run(const IgemmParams& pin, hipStream_t s) {
   // 1 per CU for the 8-wave ones); each walks nwork / grid items
   int resident = num_cus() * ((WM * WN == 4 && NST == 2) ? 2 : 1);
   const int grid_x = nwork < resident ? nwork : resident;
-  const size_t lds = (size_t)NST * (BM + BN) * kRowBytes;
+  const size_t lds = (size_t)NST * (BM + BN) * kRowBytes +
+                     (epi_stage_dedicated<BM, BN, WM, WN>() ? epi_stage_bytes<BM, BN, WM, WN>() : 0);
   auto kern = igemm_kernel<T, BM, BN, WM, WN, NST, PIPE>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -684,6 +697,14 @@ int run(const IgemmParams& pin, hipStream_t s) {
     hipLaunchKernelGGL(splitk_finish_kernel<T>, dim3(blocks), dim3(256), 0, s, p);
   }
   return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+// 8-wave 128-row tile, one workgroup per CU (3-stage ring, pipelined K loop): the mid-size grids
+// (16x16 / 32x32 feature maps) where 128-row tiles x K slices give about one work item per CU.  Versus
+// two co-resident 64-row workgroups it stages 36% fewer operand bytes per FLOP through the LDS DMA.
+inline bool mid8_ok(long t128, int splits) {
+  const long items = t128 * (splits > 1 ? splits : 1);
+  return (g_big & 16) && items >= 160 && items <= 2 * (long)num_cus();
 }
 
 template <typename T>
@@ -703,6 +724,8 @@ int dispatch(const IgemmParams& p, hipStream_t s) {
   const bool deep = (g_big & 2) && !big && t128 >= 200 && t128 < 400;
   // at most one workgroup per CU anyway: the DMA round trip (~1.1 us) is then hidden only by the
   // workgroup's own ring, so run it four stages deep instead of two
+  const bool mid8 = !big && bn >= 128 && p.epi != EPI_GEGLU && mid8_ok(t128, p.splits);
+  if (mid8) return bn == 160 ? run<T, 128, 160, 4, 2, 3, true>(p, s) : run<T, 128, 128, 4, 2, 3, true>(p, s);
   const long t64 = (long)((p.M + 63) / 64) * (p.N / bn) * (p.splits > 1 ? p.splits : 1);
   const bool lone = (g_big & 4) && small && !big && !deep && t64 <= num_cus();
   switch (bn) {
@@ -722,7 +745,7 @@ int dispatch(const IgemmParams& p, hipStream_t s) {
 }  // namespace
 
 void igemm_set_nbuf(int) {}
-void igemm_set_dbg(int f) { g_dbg = f & 0xff; g_big = (f >> 8) & 15; }   // bits 8-11 select the tile policy
+void igemm_set_dbg(int f) { g_dbg = f & 0xff; g_big = (f >> 8) & 31; }   // bits 8-12 select the tile policy
 
 int igemm_pick_bn(int n_real, int epi) {
   if (epi == EPI_GEGLU) return 128;
@@ -739,6 +762,16 @@ int igemm_plan_splits(const IgemmParams& p, int dtype) {
   const int bke = dtype == DT_BF16 ? 64 : 32;
   const int bn = p.N % 160 == 0 ? 160 : (p.N % 128 == 0 ? 128 : (p.N % 64 == 0 ? 64 : 32));
   const long tiles128 = (long)((p.M + 127) / 128) * (p.N / bn);
+  const int nk0 = p.taps * (p.C0 + p.C1) / bke;
+  if ((g_big & 16) && bn >= 128 && tiles128 < 200 && ((long)((p.M + 255) / 256) * (p.N / bn)) < 240) {
+    // 128-row 8-wave tiles: aim at one work item per CU, at least 10 K tiles per slice (a 20-tile
+    // K=1280 GEMM measured faster unsplit on 64-row tiles than split in two plus the finish pass)
+    int sp = (int)((num_cus() + tiles128 / 2) / tiles128);
+    if (sp > nk0 / 10) sp = nk0 / 10;
+    if (nk0 < 32) sp = 1;
+    if (sp > 16) sp = 16;
+    if (sp >= 2 && mid8_ok(tiles128, sp)) return sp;
+  }
   const int bm = (bn >= 128 && tiles128 < 400) ? 64 : 128;
   const long blocks = (long)((p.M + bm - 1) / bm) * (p.N / bn);
   const int nk = p.taps * (p.C0 + p.C1) / bke;
