@@ -36,27 +36,38 @@ PEAK_F32 = 157.3e12
 
 def cpu_baseline(usd, budget_s=25.0):
     """The oracle (a torch-CPU port of the reference path) on this host's cores: UNet forward,
-    B=1, L=64, fp32 - a bounded sample of the same workload."""
+    B=1, L=64, fp32 - a bounded sample of the same workload.  torch's intra-op pool is badly
+    oversubscribed with one thread per hardware thread on the 256-thread hosts (46-108 s per forward
+    against ~3 s with 32 threads), so the thread count is picked from a short sweep and reported as
+    `cores`."""
     from oracle import unet as o_unet
-    torch.set_num_threads(os.cpu_count() or 1)
     x = torch.randn(1, 12, 64, 64, generator=torch.Generator().manual_seed(0))
     t = torch.tensor(499)
-    times = []
+    ncpu = os.cpu_count() or 1
+    cands = sorted({min(ncpu, n) for n in (16, 32, 64)})
+    t_start = time.perf_counter()
+    best_nt, best = cands[0], float("inf")
+    n_fwd = 0
     with torch.no_grad():
-        t0 = time.perf_counter()
-        o_unet.unet_forward(usd, x, t)
-        first = time.perf_counter() - t0
-        spent = first
-        while spent + first < budget_s and len(times) < 5:
+        for nt in cands:
+            torch.set_num_threads(nt)
             t0 = time.perf_counter()
             o_unet.unet_forward(usd, x, t)
             dt = time.perf_counter() - t0
-            times.append(dt)
-            spent += dt
-    per = min(times) if times else first
-    return {"value": 1.0 / per, "unit": "image-steps/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle UNet forward, B=1, L=64, fp32, {1 + len(times)} forward(s), best {per:.2f}s "
-                      f"(first incl. warm-up {first:.2f}s)"}
+            n_fwd += 1
+            if dt < best:
+                best_nt, best = nt, dt
+            if time.perf_counter() - t_start > budget_s:
+                break
+        torch.set_num_threads(best_nt)
+        while time.perf_counter() - t_start + best < budget_s and n_fwd < 12:
+            t0 = time.perf_counter()
+            o_unet.unet_forward(usd, x, t)
+            best = min(best, time.perf_counter() - t0)
+            n_fwd += 1
+    return {"value": 1.0 / best, "unit": "image-steps/s", "cores": best_nt, "kind": "port",
+            "sample": f"oracle UNet forward, B=1, L=64, fp32, {n_fwd} forwards over thread counts {cands}, "
+                      f"best {best:.2f}s at {best_nt} threads ({time.perf_counter() - t_start:.0f}s of CPU work)"}
 
 
 def main():
