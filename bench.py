@@ -139,6 +139,7 @@ def main():
 
     # ---- images/s: 50-step DDIM + all-gather of latents + seg-VAE decode to logits ----
     images_per_s = None
+    postprocess = None
     if not args.no_images:
         sync_all()
         t1 = time.perf_counter()
@@ -156,6 +157,21 @@ def main():
             dist.all_reduce(e2, op=dist.ReduceOp.MAX)
         images_per_s = B * world / float(e2.item())
         assert logits.shape == (B, 128, 8 * L, 8 * L)
+        # panoptic post-processing of those logits on the GPU (HBM-bound: one read of the logits)
+        if rank == 0:
+            kw = dict(threshold_output=True, mask_th=0.5, count_th=512, overlap_th=0.5, ignore_label=0)
+            tr.postprocess_panoptic(logits, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                tr.postprocess_panoptic(logits, **kw)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            pp_ms = e0.elapsed_time(e1) / 5
+            pp_bytes = logits.numel() * 4 + 3 * B * (8 * L) ** 2 * 4      # logits read once + label/panoptic maps
+            postprocess = {"ms_per_batch": pp_ms, "achieved_GBps": pp_bytes / pp_ms / 1e6, "peak_GBps": 8000.0,
+                           "frac": pp_bytes / pp_ms / 1e6 / 8000.0, "alg_bytes": pp_bytes,
+                           "note": "wall incl. the [B,C] keep-table D2H copy and host list building"}
         del logits
 
     # ---- roofline of the dominant kernel family (igemm: conv3x3 / conv1x1 / Linear on MFMA) ----
@@ -207,6 +223,7 @@ def main():
             "images_per_s_50step_ddim_incl_decode": images_per_s,
             "whole_step_mfma_frac": (B * flop_step * args.steps / elapsed) / (PEAK_BF16 if args.dtype == "bf16" else PEAK_F32),
             "roofline": roofline,
+            "postprocess_8f1": postprocess,
             "cpu_baseline": cpu,
         }
         if cpu:

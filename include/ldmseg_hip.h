@@ -116,6 +116,19 @@ int ldmseg_vae_decode(ldmseg_vae* h, const float* z, float z_scale, int B, int L
  * max_prob [B,8L,8L] fp32 or NULL. */
 int ldmseg_vae_decode_argmax(ldmseg_vae* h, const float* z, float z_scale, int B, int L, float mask_th, int64_t ignore_label,
                              int64_t* ids, float* max_prob, void* stream);
+/* Panoptic post-processing of the evaluation loop (trainers_ldm_cond.py:1277-1313) on logits [B,C,H,W] fp32 that
+ * are already at the output size (C <= 256):
+ *   labels   [B,H,W] int32  argmax over C; -1 where threshold_output and (threshold_mode 0: max softmax prob,
+ *                           1 'topk_diff': top1 - top2 prob) < mask_th                       (:1277-1286)
+ *   counts   [B,C]  int32   pixels per label (np.unique counts, :1295)
+ *   mask_counts [B,C] int32 pixels with sigmoid(logit_c) >= mask_th (original_mask.sum(), :1303)
+ *   keep     [B,C]  uint8   0 where label == ignore_label, counts < count_th or counts / mask_counts < overlap_th
+ *                           (:1298-1306); kept labels are the reference's segments_info ids (c + 1)
+ *   panoptic [B,H,W] int32  label + 1 where kept, 0 (void) elsewhere                          (:1300,1305,1313)
+ * All outputs are device buffers owned by the caller.  One pass over the logits; nothing is copied to the host. */
+int ldmseg_panoptic_postprocess(const float* logits, int B, int C, int H, int W, int threshold_output, int threshold_mode,
+                                float mask_th, int count_th, double overlap_th, int64_t ignore_label, int32_t* labels,
+                                int32_t* panoptic, uint8_t* keep, int32_t* counts, int32_t* mask_counts, void* stream);
 /* GeneralVAESeg.encode(x) (vae.py:252-265): x [B,7,H,W] (H=W multiple of 8), moments
  * [B,8,H/8,W/8] = (mean | logvar) before the clamp.  x is used as x*in_mul+in_add
  * (encode_inputs' 2x-1, trainers_ldm_cond.py:369). */

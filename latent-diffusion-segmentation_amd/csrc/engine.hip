@@ -1095,6 +1095,18 @@ int ldmseg_bit_decode(const float* x, int B, int n_bits, int HW, int64_t* ids, v
   return 0;
 }
 
+int ldmseg_panoptic_postprocess(const float* logits, int B, int C, int H, int W, int threshold_output, int threshold_mode,
+                                float mask_th, int count_th, double overlap_th, int64_t ignore_label, int32_t* labels,
+                                int32_t* panoptic, uint8_t* keep, int32_t* counts, int32_t* mask_counts, void* stream) {
+  g_err.clear();
+  if (!logits || !labels || !panoptic || !keep || !counts || !mask_counts || B < 1 || C < 1 || C > 256 || H < 1 || W < 1 ||
+      (threshold_mode != 0 && threshold_mode != 1))
+    return fail(LDMSEG_E_ARG, "bad panoptic_postprocess argument");
+  TRY(launch_panoptic_postprocess(logits, B, C, H * W, threshold_output, threshold_mode, mask_th, count_th, overlap_th,
+                                  ignore_label, labels, panoptic, keep, counts, mask_counts, (hipStream_t)stream));
+  return 0;
+}
+
 int ldmseg_profile_enable(int enable) {
   g_prof.on = enable != 0;
   return 0;

@@ -116,6 +116,9 @@ int launch_add_noise(const float* x0, const float* noise, const int64_t* t_dev, 
                      float* out, int B, size_t per, int remove, hipStream_t s);
 int launch_axpby(const float* x, float a, float b, float* y, size_t n, hipStream_t s);  // y = a*x + b
 // bit codec of segment ids (ldmseg/data/coco.py:377-390)
+int launch_panoptic_postprocess(const float* logits, int B, int C, int HW, int threshold_output, int threshold_mode,
+                                float mask_th, int count_th, double overlap_th, int64_t ignore_label, int32_t* labels,
+                                int32_t* panoptic, uint8_t* keep, int32_t* counts, int32_t* mask_counts, hipStream_t s);
 int launch_bit_encode(const int64_t* ids, float* out, uint8_t* ignore, int B, int n, int HW, int64_t ignore_label,
                       float fill, float mul, float add, hipStream_t s);
 int launch_bit_decode(const float* x, int64_t* out, int B, int n, int HW, hipStream_t s);

@@ -34,7 +34,7 @@ class SampleCfg(C.Structure):
                 ("paste_coef", C.POINTER(C.c_float))]
 
 
-_vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+_vp, _i, _i64, _f, _sz, _d = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t, C.c_double
 
 # name -> (restype, argtypes); mirrors include/ldmseg_hip.h and include/ldmseg_hip_ops.h
 SIGNATURES = {
@@ -55,6 +55,7 @@ SIGNATURES = {
     "ldmseg_add_noise": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _i, _sz, _vp]),
     "ldmseg_remove_noise": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _i, _sz, _vp]),
     "ldmseg_sample_loop": (_i, [_vp, C.POINTER(SampleCfg), _vp, _vp, _i, _i, _vp, _vp]),
+    "ldmseg_panoptic_postprocess": (_i, [_vp, _i, _i, _i, _i, _i, _i, _f, _i, _d, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ldmseg_bit_encode": (_i, [_vp, _i, _i, _i, _i64, _f, _f, _f, _vp, _vp, _vp]),
     "ldmseg_bit_decode": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "ldmseg_last_error": (C.c_char_p, []),

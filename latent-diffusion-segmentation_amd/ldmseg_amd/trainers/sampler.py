@@ -213,6 +213,45 @@ class TrainerDiffusion(object):
                                              ignore_label=ignore_label)
 
     @torch.no_grad()
+    def postprocess_panoptic(self, masks_logits: torch.Tensor, threshold_output: bool = False,
+                             threshold_mode: str = "max", mask_th: float = 0.5, count_th: int = 512,
+                             overlap_th: float = 0.5, ignore_label: int = 0, return_stats: bool = False):
+        """The per-image post-processing loop of the evaluation (:1277-1313) in one pass on the GPU.
+
+        masks_logits [B,C,H,W] fp32 on the GPU, already at the output size.  Returns `processed_results`
+        like the reference: a list of {"panoptic_seg": (panoptic [H,W] int32 tensor (label+1, 0 = void),
+        segments_info)} with segments_info = [{"id": label+1, "category_id": 1, "isthing": True}, ...] in
+        ascending label order (np.unique order).  Only the [B,C] keep table is copied to the host.
+        """
+        from .. import _lib
+        import ctypes as C
+        x = _lib.require_cuda_f32(masks_logits, "masks_logits")
+        if x.dim() != 4:
+            raise ValueError("masks_logits must be [B,C,H,W]")
+        if threshold_mode not in ("max", "topk_diff"):
+            raise ValueError(f"unknown threshold_mode {threshold_mode!r}")
+        B, Cn, H, W = x.shape
+        dev = x.device
+        labels = torch.empty(B, H, W, dtype=torch.int32, device=dev)
+        pan = torch.empty(B, H, W, dtype=torch.int32, device=dev)
+        keep = torch.empty(B, Cn, dtype=torch.uint8, device=dev)
+        counts = torch.empty(B, Cn, dtype=torch.int32, device=dev)
+        mcounts = torch.empty(B, Cn, dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().ldmseg_panoptic_postprocess(
+                _lib.ptr(x), B, Cn, H, W, int(bool(threshold_output)), 1 if threshold_mode == "topk_diff" else 0,
+                float(mask_th), int(count_th), float(overlap_th), int(ignore_label), _lib.ptr(labels), _lib.ptr(pan),
+                _lib.ptr(keep), _lib.ptr(counts), _lib.ptr(mcounts), _lib.stream_ptr(dev)), "panoptic_postprocess")
+        keep_h = keep.cpu()
+        results = []
+        for b in range(B):
+            info = [{"id": int(c) + 1, "category_id": 1, "isthing": True} for c in torch.nonzero(keep_h[b]).flatten().tolist()]
+            results.append({"panoptic_seg": (pan[b], info)})
+        if return_stats:
+            return results, {"labels": labels, "counts": counts, "mask_counts": mcounts, "keep": keep}
+        return results
+
+    @torch.no_grad()
     def encode_inputs(self, images: torch.Tensor, sample_posterior: bool = False, encode_func=None,
                       scaling_factor: Optional[float] = None, generator=None):
         """Segmentation side of :335-394: bit maps in [0,1] -> 2x-1 -> seg-VAE -> latents * scaling."""
