@@ -193,8 +193,18 @@ def main():
         ig = fam["igemm"]
         peak = PEAK_BF16 if args.dtype == "bf16" else PEAK_F32
         ach = ig["flops"] / (ig["ms"] * 1e-3) if ig["ms"] > 0 else 0.0
+        # HBM traffic per launch of the same kernels from the PMC passes kept under profiles/ (FETCH_SIZE x2 per the
+        # gfx950 correction + WRITE_SIZE); rocprofv3 cannot run inside this process, so the figure is the committed
+        # measurement of this very command, or null when the file is absent
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(tf) and args.dtype == "bf16" and (B, L) == (8, 64):
+            with open(tf) as fh:
+                traffic = json.load(fh).get("hbm_bytes_per_launch")
         roofline = {"bound": "mfma", "kernel": "igemm_kernel (conv3x3/conv1x1/Linear)", "achieved": ach / 1e12,
-                    "peak": peak / 1e12, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                    "peak": peak / 1e12, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
+                    "traffic_unit": "HBM bytes per launch (PMC, profiles/r01_pmc_traffic.json)",
+                    "alg_bytes_per_launch": ig["bytes"] / max(1, ig["launches"]),
                     "launches": ig["launches"], "avg_launch_us": 1e3 * ig["ms"] / max(1, ig["launches"]),
                     "alg_flops_per_launch": ig["flops"] / max(1, ig["launches"]),
                     "families_ms_per_step": {k: v["ms"] / args.profile_steps for k, v in fam.items()},
