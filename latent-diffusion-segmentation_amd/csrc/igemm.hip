@@ -68,6 +68,22 @@ struct RowInfo {
   int iy0, ix0;  // top-left input coordinate (logical, before upsample shift)
 };
 
+// Ablation switches (skip DMA / MFMA / epilogue phases ...) exist only in builds with
+// -DLDMSEG_IGEMM_ABLATE: every one of them is a branch in code that runs cold once per launch.
+#ifdef LDMSEG_IGEMM_ABLATE
+#define DBG(p, bit) ((p).dbg & (bit))
+#else
+#define DBG(p, bit) 0
+#endif
+
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
@@ -236,7 +252,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(const 
     const unsigned wdst = dst + BM * kRowBytes;
 #pragma unroll
     for (int i = 0; i < WG; ++i)
-      if ((i + 1 < WG || w_last) && !(p.dbg & 2)) glds16_sbase(woff[i], wt, wdst + i * (NW * 1024));
+      if ((i + 1 < WG || w_last) && !DBG(p, 2)) glds16_sbase(woff[i], wt, wdst + i * (NW * 1024));
     ++f_kt;
     f_cc += BKE;
     if (f_cc == Ctot) { f_cc = 0; ++f_tap; }
@@ -289,8 +305,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(const 
     f32x4 bv[NF];
 #pragma unroll
     for (int a = 0; a < NF; ++a) bv[a] = *(const f32x4*)(biasp + nl + a * 16);
-#pragma unroll
-    for (int b = 0; b < MF; ++b) {
+    // One 16-row block of the wave's tile.  BI = accumulator slot that holds it.
+    auto row_block = [&](int b, auto bidx) __attribute__((always_inline)) {
+      constexpr int BI = decltype(bidx)::value;
       const int mb = m0 + wm * WTM + b * 16;
       {
         const int m = mb + lq;
@@ -302,11 +319,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(const 
           for (int a = 0; a < NF; ++a) rb[a] = *(const f32x4*)(rbp + a * 16);
 #pragma unroll
           for (int a = 0; a < NF; ++a)
-            *(f32x4*)(stg + lq * SROW + (a * 16 + lg * 4) * 4) = acc[a][b] + bv[a] + rb[a];
+            *(f32x4*)(stg + lq * SROW + (a * 16 + lg * 4) * 4) = acc[a][BI] + bv[a] + rb[a];
         } else {
 #pragma unroll
           for (int a = 0; a < NF; ++a)
-            *(f32x4*)(stg + lq * SROW + (a * 16 + lg * 4) * 4) = acc[a][b] + bv[a];
+            *(f32x4*)(stg + lq * SROW + (a * 16 + lg * 4) * 4) = acc[a][BI] + bv[a];
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's block is in LDS (per-wave region)
@@ -325,7 +342,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(const 
               const f32x4 t = *(const f32x4*)(sp + q * 16);
               v[q * 4 + 0] = t[0]; v[q * 4 + 1] = t[1]; v[q * 4 + 2] = t[2]; v[q * 4 + 3] = t[3];
             }
-            if (p.resid && !(p.dbg & 128)) {
+            if (p.resid && !DBG(p, 128)) {
               float r[E];
               Chunk<T>::unpack(*(const uint4*)((const T*)p.resid + (size_t)m * p.ldr + n), r);
 #pragma unroll
@@ -335,12 +352,27 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(const 
 #pragma unroll
               for (int e = 0; e < E; ++e) v[e] = silu_f(v[e]);
             }
-            if (!(p.dbg & 64)) *(uint4*)((T*)p.out + (size_t)m * p.ldo + n) = Chunk<T>::pack(v);
+            if (!DBG(p, 64)) *(uint4*)((T*)p.out + (size_t)m * p.ldo + n) = Chunk<T>::pack(v);
             else asm volatile("" ::"v"(v[0]), "v"(v[E - 1]));
           }
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next block overwrites
+    };
+    // Two-block tiles keep the loop ROLLED (the current block is always slot 0, the other rotates down):
+    // measured -5..10 % on the 128-row conv launches, whose single item per workgroup runs this code cold.
+    // Four-block tiles run several items per workgroup; there the rotation costs more than it saves.
+    if constexpr (MF <= 2) {
+#pragma unroll 1
+      for (int b = 0; b < MF; ++b) {
+        row_block(b, std::integral_constant<int, 0>{});
+#pragma unroll
+        for (int a = 0; a < NF; ++a)
+#pragma unroll
+          for (int j = 0; j + 1 < MF; ++j) acc[a][j] = acc[a][j + 1];
+      }
+    } else {
+      static_for<MF>([&](auto bi) __attribute__((always_inline)) { row_block(decltype(bi)::value, bi); });
     }
   };
 
@@ -365,13 +397,13 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(const 
 #pragma unroll
       for (int a = 0; a < NF; ++a) bv[a] = *(const f32x4*)(biasp + nl + a * 16);
       const int oc0 = (n0 + wn * WTN) >> 1;
-#pragma unroll
-      for (int b = 0; b < MF; ++b) {
+      auto row_block = [&](int b, auto bidx) __attribute__((always_inline)) {
+        constexpr int BI = decltype(bidx)::value;
         const int mb = m0 + wm * WTM + b * 16;
 #pragma unroll
         for (int a = 0; a < NF; a += 2) {
-          const f32x4 av = acc[a][b] + bv[a];
-          const f32x4 gv = acc[a + 1][b] + bv[a + 1];
+          const f32x4 av = acc[a][BI] + bv[a];
+          const f32x4 gv = acc[a + 1][BI] + bv[a + 1];
           f32x4 o;
 #pragma unroll
           for (int r = 0; r < 4; ++r) o[r] = av[r] * gelu_erf_f(gv[r]);
@@ -397,7 +429,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(const 
           }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      }
+      };
+      static_for<MF>([&](auto bi) __attribute__((always_inline)) { row_block(decltype(bi)::value, bi); });
     }
   };
 
@@ -412,15 +445,6 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(const 
   for (int b = 0; b < MF; ++b) {
     const int m = m0 + wm * WTM + b * 16 + (lane & 15);
     if (m >= p.M) continue;
-    if (p.splits > 1) {
-      float* dst = p.partial + ((size_t)zc * p.M + m) * p.N;
-#pragma unroll
-      for (int a = 0; a < NF; ++a) {
-        const int n = n0 + wn * WTN + a * 16 + lg * 4;
-        *(f32x4*)(dst + n) = acc[a][b];
-      }
-      continue;
-    }
     const int bimg = m / HWo;
     if (p.epi == EPI_GEGLU) {
       if constexpr (NF % 2 == 0) {
@@ -508,6 +532,20 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(const 
   }
   };
 
+  // split-K item: the raw fp32 accumulators go to this slice's slab
+  auto epilogue_partial = [&](int m0, int n0, int zc) __attribute__((always_inline)) {
+    auto row_block = [&](int b, auto bidx) __attribute__((always_inline)) {
+      constexpr int BI = decltype(bidx)::value;
+      const int m = m0 + wm * WTM + b * 16 + (lane & 15);
+      if (m < p.M) {
+        float* dst = p.partial + ((size_t)zc * p.M + m) * p.N + n0 + wn * WTN + lg * 4;
+#pragma unroll
+        for (int a = 0; a < NF; ++a) *(f32x4*)(dst + a * 16) = acc[a][BI];
+      }
+    };
+    static_for<MF>([&](auto bi) __attribute__((always_inline)) { row_block(decltype(bi)::value, bi); });
+  };
+
   // ---- prologue: NST-1 stream positions in flight, the first one landed ----
   item_setup();
   int issued = 0;
@@ -538,7 +576,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(const 
     _Pragma("unroll") for (int b = 0; b < MF; ++b) XF[b] = *(const uint4*)(xs_ + b * 16 * kRowBytes);   \
   }
 #define IGEMM_MMA(WF, XF)                                                                              \
-  if (!(p.dbg & 4)) {                                                                                  \
+  if (!DBG(p, 4)) {                                                                                  \
     _Pragma("unroll") for (int a = 0; a < NF; ++a)                                                      \
       _Pragma("unroll") for (int b = 0; b < MF; ++b) mma_kgroup<T>(WF[a], XF[b], acc[a][b]);            \
   } else {                                                                                             \
@@ -547,7 +585,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(const 
   }
       IGEMM_READ(wfA, xfA, cur, fr_c0)
       for (int kt = kb; kt < ke; ++kt) {
-        const bool more = (p.dbg & 1) ? false : fetch_next(fst);
+        const bool more = DBG(p, 1) ? false : fetch_next(fst);
         IGEMM_READ(wfB, xfB, cur, fr_c1)
         __builtin_amdgcn_sched_barrier(0);
         IGEMM_MMA(wfA, xfA)
@@ -569,19 +607,19 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(const 
 #undef IGEMM_MMA
     } else {
     for (int kt = kb; kt < ke; ++kt) {
-      const bool more = (p.dbg & 1) ? false : fetch_next(fst);
+      const bool more = DBG(p, 1) ? false : fetch_next(fst);
       const unsigned char* xs = smem + cur * kStageBytes + (wm * WTM) * kRowBytes + fr_row;
       const unsigned char* ws = smem + cur * kStageBytes + (BM + wn * WTN) * kRowBytes + fr_row;
 #pragma unroll
       for (int kg = 0; kg < 2; ++kg) {
-        if (p.dbg & 8) break;          // ablation: no LDS reads, no MFMA
+        if (DBG(p, 8)) break;          // ablation: no LDS reads, no MFMA
         const int co = kg ? fr_c1 : fr_c0;
         uint4 wf[NF], xf[MF];
 #pragma unroll
         for (int a = 0; a < NF; ++a) wf[a] = *(const uint4*)(ws + a * 16 * kRowBytes + co);
 #pragma unroll
         for (int b = 0; b < MF; ++b) xf[b] = *(const uint4*)(xs + b * 16 * kRowBytes + co);
-        if (!(p.dbg & 4)) {
+        if (!DBG(p, 4)) {
 #pragma unroll
           for (int a = 0; a < NF; ++a)
 #pragma unroll
@@ -602,13 +640,14 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(const 
     }
     }
     // the DMA of the next item's first tiles is already in flight while this epilogue runs
-    if (!(p.dbg & 16)) {
+    if (!DBG(p, 16)) {
       constexpr int E = 16 / (int)sizeof(T);
-      const bool rows_ok = p.epi == EPI_STORE && p.splits <= 1 && !(p.dbg & 32) && (p.n_valid % E == 0) &&
+      const bool rows_ok = p.epi == EPI_STORE && p.splits <= 1 && !DBG(p, 32) && (p.n_valid % E == 0) &&
                            (p.ldo % E == 0) && (!p.resid || p.ldr % E == 0);
-      const bool geglu_ok = p.epi == EPI_GEGLU && (NF % 2 == 0) && !(p.dbg & 32) && (p.ldo % E == 0);
+      const bool geglu_ok = p.epi == EPI_GEGLU && (NF % 2 == 0) && !DBG(p, 32) && (p.ldo % E == 0);
       if (rows_ok) epilogue_rows(m0c, n0c, fst);
       else if (geglu_ok) epilogue_geglu_rows(m0c, n0c, fst);
+      else if (p.splits > 1) epilogue_partial(m0c, n0c, zc);
       else epilogue(m0c, n0c, zc);
     }
     __syncthreads();   // the staging stage is handed back to the DMA ring
