@@ -70,6 +70,26 @@ def cpu_baseline(usd, budget_s=25.0):
                       f"best {best:.2f}s at {best_nt} threads ({time.perf_counter() - t_start:.0f}s of CPU work)"}
 
 
+def kl_encoder_flops(H, W):
+    """Algorithmic FLOPs (2*MACs) of the SD-1.x AutoencoderKL encoder + quant_conv per image."""
+    ch = (128, 256, 512, 512)
+    conv = lambda h, w, ci, co, k: 2.0 * h * w * ci * co * k * k
+    f = conv(H, W, 3, ch[0], 3)
+    h, w, cin = H, W, ch[0]
+    for i, co in enumerate(ch):
+        for _ in range(2):
+            f += conv(h, w, cin, co, 3) + conv(h, w, co, co, 3) + (conv(h, w, cin, co, 1) if cin != co else 0)
+            cin = co
+        if i < 3:
+            h, w = h // 2, w // 2
+            f += conv(h, w, co, co, 3)
+    n = h * w
+    f += 4 * conv(h, w, 512, 512, 3)                         # two mid resnets
+    f += 4 * 2.0 * n * 512 * 512 + 2 * 2.0 * n * n * 512     # q,k,v,proj + QK^T, PV
+    f += conv(h, w, 512, 8, 3) + conv(h, w, 8, 8, 1)
+    return f
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -174,6 +194,27 @@ def main():
                            "note": "wall incl. the [B,C] keep-table D2H copy and host list building"}
         del logits
 
+    # ---- RGB image encoder (once per image, before the loop) ----
+    image_encoder = None
+    if rank == 0 and not args.no_images:
+        from ldmseg_amd.models import GeneralVAEImage
+        isd = weights.generate(weights.vae_image_schema(), seed=11, norm_keys=weights.VAE_IMAGE_NORM_KEYS)
+        enc = GeneralVAEImage(isd, device=dev, compute_dtype=args.dtype)
+        img = torch.rand(B, 3, 8 * L, 8 * L, device=dev)
+        enc.encode_moments(img, 2.0, -1.0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            enc.encode_moments(img, 2.0, -1.0)
+        e1.record()
+        torch.cuda.synchronize(dev)
+        ems = e0.elapsed_time(e1) / 3
+        efl = B * kl_encoder_flops(8 * L, 8 * L)
+        image_encoder = {"ms_per_batch": ems, "images_per_s": B / ems * 1e3, "achieved_TFLOPs": efl / ems / 1e9,
+                         "peak_TFLOPs": (PEAK_BF16 if args.dtype == "bf16" else PEAK_F32) / 1e12,
+                         "alg_gflop_per_image": efl / B / 1e9}
+        del enc, img, isd
+
     # ---- roofline of the dominant kernel family (igemm: conv3x3 / conv1x1 / Linear on MFMA) ----
     roofline = None
     fam = {}
@@ -234,6 +275,7 @@ def main():
             "whole_step_mfma_frac": (B * flop_step * args.steps / elapsed) / (PEAK_BF16 if args.dtype == "bf16" else PEAK_F32),
             "roofline": roofline,
             "postprocess_8f1": postprocess,
+            "image_encoder_8f2": image_encoder,
             "cpu_baseline": cpu,
         }
         if cpu:

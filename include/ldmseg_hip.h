@@ -47,6 +47,7 @@ extern "C" {
 
 typedef struct ldmseg_unet ldmseg_unet;  /* opaque */
 typedef struct ldmseg_vae ldmseg_vae;    /* opaque */
+typedef struct ldmseg_vae_image ldmseg_vae_image;  /* opaque */
 
 /* ---- UNet: ldmseg/models/unet.py::UNet (UNet2DConditionModel, SD-1.x topology) ---------- */
 typedef struct {
@@ -139,6 +140,31 @@ int ldmseg_vae_encode(ldmseg_vae* h, const float* x, float in_mul, float in_add,
 int ldmseg_vae_posterior(const float* moments, const float* noise, float out_scale, int B, int l, float* out,
                          void* stream);
 int64_t ldmseg_vae_num_params(const ldmseg_vae* h);
+
+/* ---- image VAE encoder: ldmseg/models/vae.py:36-39 GeneralVAEImage(AutoencoderKL), decoder removed
+ * (tools/main_ldm.py:137-139); used as encode_func in TrainerDiffusion.encode_inputs (trainers_ldm_cond.py:360-375).
+ * SD-1.x VAE encoder: conv_in 3->128, down blocks 128/256/512/512 with two temb-free resnets each (GroupNorm 32,
+ * eps 1e-6, SiLU), stride-2 convs with F.pad(0,1,0,1), mid block resnet / single-head attention (C=512) / resnet,
+ * conv_norm_out + SiLU + conv_out 512->8, quant_conv 8->8.  The arithmetic is diffusers' (not vendored by the
+ * reference): parity is pinned against oracle/vae_image.py only. */
+typedef struct {
+  int32_t compute_dtype;    /* LDMSEG_F32 | LDMSEG_BF16 */
+  int32_t device;
+} ldmseg_vae_image_cfg;
+/* keys: the 'vae_image' entry of ldmseg.pt (trainers_ldm_cond.py:1805) / AutoencoderKL.state_dict():
+ * encoder.conv_in, encoder.down_blocks.{0..3}.resnets.{0,1}.{norm1,conv1,norm2,conv2[,conv_shortcut]},
+ * encoder.down_blocks.{0..2}.downsamplers.0.conv, encoder.mid_block.resnets.{0,1}.*,
+ * encoder.mid_block.attentions.0.{group_norm, query|to_q, key|to_k, value|to_v, proj_attn|to_out.0},
+ * encoder.conv_norm_out, encoder.conv_out, quant_conv (decoder.* / post_quant_conv.* are ignored). */
+int ldmseg_vae_image_create(const ldmseg_vae_image_cfg* cfg, int n_weights, const char* const* names,
+                            const void* const* dev_ptrs, const int64_t* numels, ldmseg_vae_image** out);
+void ldmseg_vae_image_destroy(ldmseg_vae_image* h);
+int64_t ldmseg_vae_image_num_params(const ldmseg_vae_image* h);
+/* AutoencoderKL.encode(x).latent_dist parameters: x [B,3,H,W] fp32 (used as x*in_mul+in_add: encode_inputs' 2x-1,
+ * trainers_ldm_cond.py:369), H, W multiples of 8 with (H/8)*(W/8) a multiple of 64 -> moments [B,8,H/8,W/8]
+ * (mean | logvar before the clamp); feed ldmseg_vae_posterior for .mode()/.sample() and the scaling factor. */
+int ldmseg_vae_image_encode(ldmseg_vae_image* h, const float* x, float in_mul, float in_add, int B, int H, int W,
+                            float* moments, void* stream);
 
 /* ---- scheduler: ldmseg/schedulers/ddim_scheduler.py --------------------------------------- */
 /* DDIMNoiseScheduler.step (:218-269), elementwise over n floats.  The four coefficients are

@@ -106,6 +106,14 @@ __device__ __forceinline__ float row16_sum(float v) {
   v += dpp_f<0x140>(v);
   return v;
 }
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_f<0xB1>(v));
+  v = fmaxf(v, dpp_f<0x4E>(v));
+  v = fmaxf(v, dpp_f<0x141>(v));
+  v = fmaxf(v, dpp_f<0x140>(v));
+  return v;
+}
+__device__ __forceinline__ float wave64_max(float v) { return xor32_max(xor16_max(row16_max(v))); }
 // all-lanes sum of a wave64, result in every lane
 __device__ __forceinline__ float wave64_sum(float v) { return xor32_sum(xor16_sum(row16_sum(v))); }
 

@@ -277,18 +277,19 @@ struct Exec {
 
   // conv3x3 / 1x1 over NHWC `x` (optionally channel-concatenated with `x2`)
   int conv(const ConvW& w, const Act& x, const Act* x2, Act* out, int stride, int up, bool persist,
-           const float* rowbias, int rb_stride, const Act* resid, int silu = 0) {
+           const float* rowbias, int rb_stride, const Act* resid, int silu = 0, int pad = -1) {
     const int ctot = x.C + (x2 ? x2->C : 0);
     if (ctot != w.cin_pad) return fail(LDMSEG_E_SHAPE, "conv: channel mismatch");
     const int Hl = up ? 2 * x.H : x.H, Wl = up ? 2 * x.W : x.W;
-    const int Ho = (w.taps == 9 && stride == 2) ? (Hl - 1) / 2 + 1 : Hl;
-    const int Wo = (w.taps == 9 && stride == 2) ? (Wl - 1) / 2 + 1 : Wl;
+    // stride 2: pad 1 both sides (UNet downsample_padding=1) or pad 0 + one zero row/column at the bottom/right
+    const int Ho = (w.taps == 9 && stride == 2) ? (pad == 0 ? Hl / 2 : (Hl - 1) / 2 + 1) : Hl;
+    const int Wo = (w.taps == 9 && stride == 2) ? (pad == 0 ? Wl / 2 : (Wl - 1) / 2 + 1) : Wl;
     *out = new_act(w.n_valid, Ho, Wo, persist);
     IgemmParams p;
     p.src0 = x.p; p.C0 = x.C;
     if (x2) { p.src1 = x2->p; p.C1 = x2->C; }
     p.B = B; p.Hi = x.H; p.Wi = x.W; p.Ho = Ho; p.Wo = Wo;
-    p.taps = w.taps; p.stride = stride; p.up = up;
+    p.taps = w.taps; p.stride = stride; p.up = up; p.pad = pad;
     p.M = B * Ho * Wo; p.N = w.N; p.n_valid = w.n_valid;
     p.W = w.w; p.bias = w.bias;
     p.rowbias = rowbias; p.rb_stride = rb_stride;
@@ -895,6 +896,172 @@ int vae_encode_impl(ldmseg_vae* v, const float* x, float mul, float add, int B, 
 
 }  // namespace
 
+// =================================================================== image VAE encoder (AutoencoderKL, SD-1.x)
+struct ldmseg_vae_image {
+  ldmseg_vae_image_cfg cfg{};
+  int dt = DT_BF16;
+  DeviceArena arena;
+  Workspace ws;
+  void* ws_mem = nullptr;
+  size_t ws_cap = 0;
+  int64_t nparams = 0;
+  ConvW conv_in, downs[3], conv_out, quant;
+  ResnetW down[4][2], mid[2];
+  NormW attn_gn, norm_out;
+  ConvW q, k, proj;
+  void* wv = nullptr;       // value projection [512][512], used as the X operand of the V^T GEMM
+  float* bv = nullptr;
+  ~ldmseg_vae_image() {
+    arena.release();
+    if (ws_mem) (void)hipFree(ws_mem);
+  }
+};
+
+namespace {
+
+constexpr int kKLCh[4] = {128, 256, 512, 512};
+constexpr int kKLMid = 512;
+
+int klenc_build(ldmseg_vae_image* v, const WeightMap& wm) {
+  hipStream_t s = nullptr;
+  Builder b{&v->arena, &wm, v->dt, s};
+  const int cp = bke(v->dt);
+  TRY(b.conv("encoder.conv_in", kKLCh[0], 3, 3, cp, &v->conv_in));
+  int cin = kKLCh[0], dummy = 0;
+  for (int i = 0; i < 4; ++i) {
+    for (int j = 0; j < 2; ++j) {
+      TRY(build_resnet(b, "encoder.down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j) + ".", cin, kKLCh[i],
+                       &dummy, &v->down[i][j]));
+      cin = kKLCh[i];
+    }
+    if (i < 3) TRY(b.conv("encoder.down_blocks." + std::to_string(i) + ".downsamplers.0.conv", cin, cin, 3, cin, &v->downs[i]));
+  }
+  for (int j = 0; j < 2; ++j)
+    TRY(build_resnet(b, "encoder.mid_block.resnets." + std::to_string(j) + ".", kKLMid, kKLMid, &dummy, &v->mid[j]));
+  // single-head attention block; diffusers 0.16.1 names (query/key/value/proj_attn) or the later to_q/.../to_out.0
+  const std::string ap = "encoder.mid_block.attentions.0.";
+  const bool old_names = wm.m.count(ap + "query.weight") != 0;
+  const std::string qn = old_names ? "query" : "to_q", kn = old_names ? "key" : "to_k", vn = old_names ? "value" : "to_v",
+                    pn = old_names ? "proj_attn" : "to_out.0";
+  TRY(b.norm(ap + "group_norm", kKLMid, &v->attn_gn));
+  TRY(b.conv(ap + qn, kKLMid, kKLMid, 1, kKLMid, &v->q));
+  TRY(b.conv(ap + kn, kKLMid, kKLMid, 1, kKLMid, &v->k));
+  TRY(b.conv(ap + pn, kKLMid, kKLMid, 1, kKLMid, &v->proj));
+  {
+    const float* w;
+    TRY(wm.get(ap + vn + ".weight", (int64_t)kKLMid * kKLMid, &w));
+    TRY(b.arena->alloc(&v->wv, (size_t)kKLMid * kKLMid * esize(v->dt)));
+    TRY(launch_repack_conv(w, v->wv, kKLMid, kKLMid, 1, 1, kKLMid, kKLMid, v->dt, s));
+    b.nparams += (int64_t)kKLMid * kKLMid;
+    TRY(b.f32_copy(ap + vn + ".bias", kKLMid, &v->bv));
+  }
+  TRY(b.norm("encoder.conv_norm_out", kKLMid, &v->norm_out));
+  // conv_out writes its 8 channels into a full K tile (zero padded) so that quant_conv (1x1) can consume it
+  TRY(b.conv("encoder.conv_out", 8, kKLMid, 3, kKLMid, &v->conv_out, true, cp));
+  TRY(b.conv("quant_conv", 8, 8, 1, cp, &v->quant, true, 0, EPI_NCHW_F32));
+  TRY(b.finish());
+  v->nparams = b.nparams;
+  return 0;
+}
+
+// diffusers ResnetBlock2D with temb=None, eps 1e-6 (AutoencoderKL)
+int run_resnet_plain(Exec& ex, const ResnetW& r, const Act& x, Act* out) {
+  Workspace* ws = ex.ws;
+  const size_t m = ws->mark();
+  Act n1, h1, n2, sc;
+  TRY(ex.groupnorm(r.norm1, x, nullptr, 1e-6f, 1, &n1));
+  TRY(ex.conv(r.conv1, n1, nullptr, &h1, 1, 0, false, nullptr, 0, nullptr));
+  TRY(ex.groupnorm(r.norm2, h1, nullptr, 1e-6f, 1, &n2));
+  const Act* resid = &x;
+  if (r.has_shortcut) {
+    TRY(ex.conv(r.shortcut, x, nullptr, &sc, 1, 0, false, nullptr, 0, nullptr));
+    resid = &sc;
+  }
+  TRY(ex.conv(r.conv2, n2, nullptr, out, 1, 0, true, nullptr, 0, resid));
+  ws->reset(m);
+  return 0;
+}
+
+// AttentionBlock of the mid block: one head of width C=512 over the N=H*W tokens of each image.  Built from the
+// implicit-GEMM kernel: S_b = Q_b K_b^T (fp32 rows) -> row softmax -> V_b^T = W_v X_b^T -> O_b = P_b V_b (+b_v, since
+// softmax rows sum to one) -> proj + residual.  Runs once per image, not per denoising step.
+int klenc_attention(Exec& ex, const ldmseg_vae_image* v, const Act& x, Act* out) {
+  Workspace* ws = ex.ws;
+  const size_t m = ws->mark();
+  const int C = kKLMid, N = x.H * x.W;
+  const size_t es = esize(ex.dt);
+  if (N % 64 != 0) return fail(LDMSEG_E_SHAPE, "image VAE attention: (H/8)*(W/8) must be a multiple of 64");
+  Act n, q, k, att;
+  TRY(ex.groupnorm(v->attn_gn, x, nullptr, 1e-6f, 0, &n));
+  TRY(ex.conv(v->q, n, nullptr, &q, 1, 0, false, nullptr, 0, nullptr));
+  TRY(ex.conv(v->k, n, nullptr, &k, 1, 0, false, nullptr, 0, nullptr));
+  att = ex.new_act(C, x.H, x.W, false);
+  float* S = (float*)ws->scratch((size_t)N * N * sizeof(float));
+  void* P = ws->scratch((size_t)N * N * es);
+  void* Vt = ws->scratch((size_t)C * N * es);
+  for (int b = 0; b < ex.B; ++b) {
+    const size_t off = (size_t)b * N * C * es;
+    {
+      IgemmParams p;                                   // S = Q_b K_b^T
+      p.src0 = (const char*)q.p + off; p.C0 = C; p.B = 1; p.Hi = p.Ho = N; p.Wi = p.Wo = 1;
+      p.M = N; p.N = N; p.n_valid = N; p.W = (const char*)k.p + off; p.out = S; p.ldo = N; p.epi = EPI_ROWS_F32;
+      TRY(ex.igemm(p));
+    }
+    {
+      ProfScope ps(4, ex.s, 0, (double)N * N * (4 + es), ex.dry());
+      if (!ex.dry()) TRY(launch_softmax_rows(S, P, N, N, 1.0f / std::sqrt((float)C), ex.dt, ex.s));
+    }
+    {
+      IgemmParams p;                                   // V_b^T [C][N] = W_v X_b^T
+      p.src0 = v->wv; p.C0 = C; p.B = 1; p.Hi = p.Ho = C; p.Wi = p.Wo = 1;
+      p.M = C; p.N = N; p.n_valid = N; p.W = (const char*)n.p + off; p.out = Vt; p.ldo = N;
+      TRY(ex.igemm(p));
+    }
+    {
+      IgemmParams p;                                   // O_b = P_b V_b + b_v
+      p.src0 = P; p.C0 = N; p.B = 1; p.Hi = p.Ho = N; p.Wi = p.Wo = 1;
+      p.M = N; p.N = C; p.n_valid = C; p.W = Vt; p.bias = v->bv; p.out = (char*)att.p + off; p.ldo = C;
+      TRY(ex.igemm(p));
+    }
+  }
+  TRY(ex.conv(v->proj, att, nullptr, out, 1, 0, true, nullptr, 0, &x));
+  ws->reset(m);
+  return 0;
+}
+
+int klenc_encode_impl(ldmseg_vae_image* v, const float* x, float mul, float add, int B, int H, int W, float* moments,
+                      hipStream_t s, bool dry, size_t scratch_base) {
+  Workspace* ws = &v->ws;
+  ws->begin(dry, scratch_base);
+  Exec ex{ws, v->dt, B, s};
+  const int dt = v->dt;
+  Act xin = ex.new_act(bke(dt), H, W, true);
+  {
+    ProfScope ps(4, s, 0, 0, dry);
+    if (!dry) TRY(launch_pack_nchw(x, xin.p, B, 3, H * W, bke(dt), mul, add, dt, s));
+  }
+  Act h, o;
+  TRY(ex.conv(v->conv_in, xin, nullptr, &h, 1, 0, true, nullptr, 0, nullptr));
+  for (int i = 0; i < 4; ++i) {
+    for (int j = 0; j < 2; ++j) { TRY(run_resnet_plain(ex, v->down[i][j], h, &o)); h = o; }
+    if (i < 3) { TRY(ex.conv(v->downs[i], h, nullptr, &o, 2, 0, true, nullptr, 0, nullptr, 0, 0)); h = o; }
+  }
+  TRY(run_resnet_plain(ex, v->mid[0], h, &o)); h = o;
+  TRY(klenc_attention(ex, v, h, &o)); h = o;
+  TRY(run_resnet_plain(ex, v->mid[1], h, &o)); h = o;
+  Act g, c8;
+  TRY(ex.groupnorm(v->norm_out, h, nullptr, 1e-6f, 1, &g));
+  TRY(ex.conv(v->conv_out, g, nullptr, &c8, 1, 0, true, nullptr, 0, nullptr));
+  IgemmParams p;
+  p.src0 = c8.p; p.C0 = c8.C; p.B = B; p.Hi = p.Ho = h.H; p.Wi = p.Wo = h.W;
+  p.taps = 1; p.M = B * h.H * h.W; p.N = v->quant.N; p.n_valid = 8;
+  p.W = v->quant.w; p.bias = v->quant.bias; p.out = moments; p.epi = EPI_NCHW_F32;
+  TRY(ex.igemm(p));
+  return 0;
+}
+
+}  // namespace
+
 // =================================================================== C ABI
 extern "C" {
 
@@ -1003,6 +1170,37 @@ int ldmseg_vae_encode(ldmseg_vae* h, const float* x, float in_mul, float in_add,
   const size_t persist = rup(h->ws.persist_peak, 4096), scratch = rup(h->ws.scratch_peak, 4096);
   TRY(ensure_ws(&h->ws_mem, &h->ws_cap, &h->ws, persist + scratch));
   return vae_encode_impl(h, x, in_mul, in_add, B, H, moments, (hipStream_t)stream, false, persist);
+}
+
+int ldmseg_vae_image_create(const ldmseg_vae_image_cfg* cfg, int n_weights, const char* const* names,
+                            const void* const* dev_ptrs, const int64_t* numels, ldmseg_vae_image** out) {
+  g_err.clear();
+  if (!cfg || !out) return fail(LDMSEG_E_ARG, "null argument");
+  if (cfg->compute_dtype != LDMSEG_F32 && cfg->compute_dtype != LDMSEG_BF16) return fail(LDMSEG_E_ARG, "bad compute_dtype");
+  HIP_TRY(hipSetDevice(cfg->device));
+  TRY(check_arch(cfg->device));
+  WeightMap wm;
+  TRY(make_weight_map(n_weights, names, dev_ptrs, numels, &wm));
+  ldmseg_vae_image* v = new ldmseg_vae_image();
+  v->cfg = *cfg;
+  v->dt = cfg->compute_dtype == LDMSEG_BF16 ? DT_BF16 : DT_F32;
+  const int r = klenc_build(v, wm);
+  if (r != 0) { delete v; return r; }
+  *out = v;
+  return 0;
+}
+void ldmseg_vae_image_destroy(ldmseg_vae_image* h) { delete h; }
+int64_t ldmseg_vae_image_num_params(const ldmseg_vae_image* h) { return h ? h->nparams : 0; }
+
+int ldmseg_vae_image_encode(ldmseg_vae_image* h, const float* x, float in_mul, float in_add, int B, int H, int W,
+                            float* moments, void* stream) {
+  g_err.clear();
+  if (!h || !x || !moments) return fail(LDMSEG_E_ARG, "null argument");
+  if (B < 1 || H < 8 || W < 8 || H % 8 || W % 8) return fail(LDMSEG_E_SHAPE, "H and W must be multiples of 8");
+  TRY(klenc_encode_impl(h, x, in_mul, in_add, B, H, W, moments, (hipStream_t)stream, true, 0));
+  const size_t persist = rup(h->ws.persist_peak, 4096), scratch = rup(h->ws.scratch_peak, 4096);
+  TRY(ensure_ws(&h->ws_mem, &h->ws_cap, &h->ws, persist + scratch));
+  return klenc_encode_impl(h, x, in_mul, in_add, B, H, W, moments, (hipStream_t)stream, false, persist);
 }
 
 int ldmseg_vae_posterior(const float* moments, const float* noise, float out_scale, int B, int l, float* out,
@@ -1144,7 +1342,10 @@ int ldmseg_profile_read(int family, int64_t* launches, double* total_ms, double*
 int ldmseg_debug_set(int key, int value) {
   if (key == 0) { igemm_set_nbuf(value); return 0; }
   if (key == 2) { attention_set_qf1(value); return 0; }
-  if (key == 1) { igemm_set_dbg(value); return 0; }   // bits 0-7 ablation flags, bits 8-9 tile policy
+  if (key == 1) { igemm_set_dbg(value); return 0; }   // bits 0-7 ablation flags (LDMSEG_IGEMM_ABLATE builds), bits 8-12 tile policy
+  static unsigned long long ts_ptr = 0;                // keys 3/4: low/high half of a device stamp buffer (ablate builds)
+  if (key == 3) { ts_ptr = (ts_ptr & 0xffffffff00000000ull) | (unsigned)value; igemm_set_tsbuf((void*)(uintptr_t)ts_ptr); return 0; }
+  if (key == 4) { ts_ptr = (ts_ptr & 0xffffffffull) | ((unsigned long long)(unsigned)value << 32); igemm_set_tsbuf((void*)(uintptr_t)ts_ptr); return 0; }
   return fail(LDMSEG_E_ARG, "unknown debug key");
 }
 

@@ -72,8 +72,11 @@ struct RowInfo {
 // -DLDMSEG_IGEMM_ABLATE: every one of them is a branch in code that runs cold once per launch.
 #ifdef LDMSEG_IGEMM_ABLATE
 #define DBG(p, bit) ((p).dbg & (bit))
+#define STAMP(p, slot)                                                                              \
+  if ((p).ts && threadIdx.x == 0) (p).ts[(size_t)blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memtime();
 #else
 #define DBG(p, bit) 0
+#define STAMP(p, slot)
 #endif
 
 template <int N, typename F>
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(const 
   const int nk_total = K / BKE;
   const int Hlog = p.up ? 2 * p.Hi : p.Hi;
   const int Wlog = p.up ? 2 * p.Wi : p.Wi;
-  const int pad = (p.taps == 9) ? 1 : 0;
+  const int pad = (p.taps == 9) ? (p.pad >= 0 ? p.pad : 1) : 0;
   const int HWo = p.Ho * p.Wo;
 
   // ---- direct-to-LDS staging (global_load_lds_dwordx4): one wave instruction fills one 8-row
@@ -309,6 +312,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(const 
     auto row_block = [&](int b, auto bidx) __attribute__((always_inline)) {
       constexpr int BI = decltype(bidx)::value;
       const int mb = m0 + wm * WTM + b * 16;
+      STAMP(p, 6 + 2 * b)
       {
         const int m = mb + lq;
         const int bimg = (m < p.M ? m : p.M - 1) / HWo;
@@ -327,6 +331,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(const 
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's block is in LDS (per-wave region)
+      STAMP(p, 7 + 2 * b)
 #pragma unroll
       for (int i = 0; i < (NCH + 63) / 64; ++i) {
         const int c = lane + i * 64;
@@ -509,6 +514,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(const 
         } else {
           *(f32x4*)o = f32x4{v[0], v[1], v[2], v[3]};
         }
+      } else if (p.epi == EPI_ROWS_F32) {      // fp32 row-major regardless of the compute dtype (attention scores)
+        *(f32x4*)((float*)p.out + (size_t)m * p.ldo + n) = f32x4{v[0], v[1], v[2], v[3]};
       } else if (p.epi == EPI_NCHW_F32) {
         const int pix = m - bimg * HWo;
         float* o = (float*)p.out + ((size_t)bimg * p.n_valid + n) * HWo + pix;
@@ -547,6 +554,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(const 
   };
 
   // ---- prologue: NST-1 stream positions in flight, the first one landed ----
+  STAMP(p, 0)
   item_setup();
   int issued = 0;
 #pragma unroll
@@ -556,6 +564,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(const 
   else wait_dma(std::integral_constant<int, 0>{});
   __syncthreads();
 
+  STAMP(p, 1)
   int cur = 0;            // stage of the tile being computed
   int fst = NST - 1;      // stage the next DMA goes to
   for (int c_item = first_item; c_item < nwork; c_item += G) {
@@ -640,6 +649,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(const 
     }
     }
     // the DMA of the next item's first tiles is already in flight while this epilogue runs
+    if (c_item == first_item) { STAMP(p, 2) }
     if (!DBG(p, 16)) {
       constexpr int E = 16 / (int)sizeof(T);
       const bool rows_ok = p.epi == EPI_STORE && p.splits <= 1 && !DBG(p, 32) && (p.n_valid % E == 0) &&
@@ -650,7 +660,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(const 
       else if (p.splits > 1) epilogue_partial(m0c, n0c, zc);
       else epilogue(m0c, n0c, zc);
     }
+    if (c_item == first_item) { STAMP(p, 3) }
     __syncthreads();   // the staging stage is handed back to the DMA ring
+    if (c_item == first_item) { STAMP(p, 4) }
 #pragma unroll
     for (int a = 0; a < NF; ++a)
 #pragma unroll
@@ -705,6 +717,7 @@ const void* zero_page() {
 }
 
 int g_dbg = 0;       // ablation flags (profiling experiments only)
+void* g_tsbuf = nullptr;   // s_memtime stamp buffer (LDMSEG_IGEMM_ABLATE builds)
 int g_big = 29;      // bit0: 8-wave 256-row tiles with a 3-stage ring (-0.15 ms per forward, on);
                      // bit1: 4-stage ring, one workgroup per CU, for mid-size grids (+0.5 ms, off)
 
@@ -712,6 +725,7 @@ template <typename T, int BM, int BN, int WM, int WN, int NST = 2, bool PIPE = f
 int run(const IgemmParams& pin, hipStream_t s) {
   IgemmParams p = pin;
   p.dbg = g_dbg;
+  p.ts = (unsigned long long*)g_tsbuf;
   p.zeros = zero_page();
   if (!p.zeros) return -3;
   const int mt = (p.M + BM - 1) / BM, nt = p.N / BN;
@@ -784,6 +798,7 @@ int dispatch(const IgemmParams& p, hipStream_t s) {
 }  // namespace
 
 void igemm_set_nbuf(int) {}
+void igemm_set_tsbuf(void* b) { g_tsbuf = b; }
 void igemm_set_dbg(int f) { g_dbg = f & 0xff; g_big = (f >> 8) & 31; }   // bits 8-12 select the tile policy
 
 int igemm_pick_bn(int n_real, int epi) {

@@ -14,6 +14,7 @@ enum Epilogue : int {
   EPI_GEGLU = 1,   // packed (a,g) 16-column interleave -> out[m][n/2] = a*gelu(g)
   EPI_NCHW_F32 = 2,  // out is float NCHW [B][n_valid][Ho*Wo]  (conv_out, VAE heads)
   EPI_CONVT2 = 3,  // ConvTranspose2d k2s2: n = tap*Cout + co scattered to (2y+dy,2x+dx)
+  EPI_ROWS_F32 = 4,  // out is float row-major [M][ldo] whatever the compute dtype (attention scores of the image VAE)
 };
 
 struct IgemmParams {
@@ -22,6 +23,8 @@ struct IgemmParams {
   int C0 = 0, C1 = 0;
   int B = 0, Hi = 0, Wi = 0, Ho = 0, Wo = 0;
   int taps = 1;     // 1 (1x1 conv / Linear) or 9 (3x3, pad 1)
+  int pad = -1;     // top/left zero padding of a 3x3 conv; -1 = 1.  0 with stride 2 = F.pad(x,(0,1,0,1)) + conv(pad 0)
+                    // (diffusers Downsample2D(padding=0) of the AutoencoderKL encoder); the bottom/right edge is bounds-checked
   int stride = 1;   // 1 | 2
   int up = 0;       // nearest x2 upsample folded into the gather (Upsample2D)
   int M = 0;        // B*Ho*Wo
@@ -44,6 +47,7 @@ struct IgemmParams {
   float* partial = nullptr;
   const void* zeros = nullptr;   // >= 16 B of zeros (set by the launcher)
   int dbg = 0;                   // ablation flags for profiling experiments (results are wrong when != 0)
+  unsigned long long* ts = nullptr;   // LDMSEG_IGEMM_ABLATE builds: per-workgroup s_memtime stamps (wave 0)
 };
 
 // returns 0 or a negative error (bad shape)
@@ -52,6 +56,7 @@ size_t igemm_partial_bytes(const IgemmParams& p);
 int igemm_plan_splits(const IgemmParams& p, int dtype);
 void attention_set_qf1(int v);    // tuning knob: force 16 query rows per wave
 void igemm_set_nbuf(int n);
+void igemm_set_tsbuf(void* dev_buf);   // LDMSEG_IGEMM_ABLATE builds only
 void igemm_set_dbg(int flags);   // ablation flags (profiling only)   // K-loop ring depth (2, 3, 4) - tuning knob
 // tile the launcher would pick (for weight padding): N tile size for a given N.
 int igemm_pick_bn(int n_real, int epi);
@@ -114,6 +119,8 @@ int launch_inpaint_paste(float* cur, const float* z0, const float* noise, const 
 // add_noise / remove_noise with per-sample timesteps (ddim_scheduler.py:155-216)
 int launch_add_noise(const float* x0, const float* noise, const int64_t* t_dev, const float* ac_dev, float scale,
                      float* out, int B, size_t per, int remove, hipStream_t s);
+// softmax(scale * s) over the last dim of fp32 scores [rows][n] -> probabilities in the compute dtype [rows][n]
+int launch_softmax_rows(const float* s, void* p, int rows, int n, float scale, int dtype, hipStream_t st);
 int launch_axpby(const float* x, float a, float b, float* y, size_t n, hipStream_t s);  // y = a*x + b
 // bit codec of segment ids (ldmseg/data/coco.py:377-390)
 int launch_panoptic_postprocess(const float* logits, int B, int C, int HW, int threshold_output, int threshold_mode,

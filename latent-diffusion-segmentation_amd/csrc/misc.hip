@@ -151,6 +151,35 @@ __global__ __launch_bounds__(256) void bilinear_argmax_kernel(const T* x, int64_
   if (prob) prob[o] = pmax;
 }
 
+// ---------------------------------------------------------------- row softmax (single-head attention of the image VAE)
+// one wave per row; three passes over a row that stays in L2 (16-64 KB): max, sum of exp, normalise
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* s, T* p, int rows, int n, float scale) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* r = s + (size_t)row * n;
+  float m = -INFINITY;
+  for (int i = lane * 4; i < n; i += 256) {
+    const f32x4 v = *(const f32x4*)(r + i);
+    m = fmaxf(fmaxf(m, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+  }
+  m = wave64_max(m) * scale;     // scale > 0
+  float sum = 0.f;
+  for (int i = lane * 4; i < n; i += 256) {
+    const f32x4 v = *(const f32x4*)(r + i);
+    sum += (__expf(v[0] * scale - m) + __expf(v[1] * scale - m)) + (__expf(v[2] * scale - m) + __expf(v[3] * scale - m));
+  }
+  sum = wave64_sum(sum);
+  const float inv = 1.0f / sum;
+  T* o = p + (size_t)row * n;
+  for (int i = lane * 4; i < n; i += 256) {
+    const f32x4 v = *(const f32x4*)(r + i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[i + e] = from_f32<T>(__expf(v[e] * scale - m) * inv);
+  }
+}
+
 // ---------------------------------------------------------------- weight repack
 template <typename T>
 __global__ void repack_conv_kernel(const float* w, T* out, int Co, int Ci, int KH, int KW, int Npad, int Cipad) {
@@ -288,6 +317,13 @@ int launch_bilinear2x_argmax(const void* x, int64_t* ids, float* prob, int B, in
     if (C % 4) return -2;
     hipLaunchKernelGGL(bilinear_argmax_kernel<float>, grid, block, 0, s, (const float*)x, ids, prob, H, W, C, mask_th, ignore_label);
   }
+  return ok();
+}
+
+int launch_softmax_rows(const float* sc, void* p, int rows, int n, float scale, int dtype, hipStream_t st) {
+  if (n % 4) return -2;
+  if (dtype == DT_BF16) hipLaunchKernelGGL(softmax_rows_kernel<bf16_t>, dim3((rows + 3) / 4), dim3(256), 0, st, sc, (bf16_t*)p, rows, n, scale);
+  else hipLaunchKernelGGL(softmax_rows_kernel<float>, dim3((rows + 3) / 4), dim3(256), 0, st, sc, (float*)p, rows, n, scale);
   return ok();
 }
 

@@ -300,7 +300,9 @@ int run_gn(const GNParams& p, hipStream_t s) {
   constexpr int PC = Chunk<T>::N;
   const int C = p.C0 + p.C1;
   if (C % p.groups != 0 || C % PC != 0 || p.C0 % PC != 0 || p.groups > 64) return -2;
-  if (C / p.groups < PC) return -2;               // a 16-B vector may span at most two groups
+  // a 16-B vector may span at most two groups: cpg >= PC, or exactly two whole groups per vector
+  // (128 channels in bf16: cpg 4, PC 8 - the image VAE's first level)
+  if (C / p.groups < PC && 2 * (C / p.groups) != PC) return -2;
   if (C / PC > 256 * kMaxIter) return -2;
   {
     constexpr int EPU = 4 / (int)sizeof(T);

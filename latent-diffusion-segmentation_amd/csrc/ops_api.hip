@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <string>
+#include <cstdlib>
 #include <vector>
 
 #include "../../include/ldmseg_hip.h"
@@ -109,6 +110,9 @@ int ldmseg_op_conv2d(const float* x, const float* x2, const float* w, const floa
   p.src0 = xp; p.C0 = c0; p.src1 = x2p; p.C1 = c1;
   p.B = B; p.Hi = H; p.Wi = W; p.Ho = Ho; p.Wo = Wo; p.taps = k * k; p.stride = stride; p.up = up;
   p.M = B * Ho * Wo; p.N = Np; p.n_valid = Co; p.W = wp; p.bias = bp; p.out = out; p.epi = EPI_NCHW_F32;
+  if (std::getenv("LDMSEG_OP_TIMING_NHWC")) {   // kernel-timing experiments: the engine's NHWC store epilogue (output discarded)
+    p.out = t.get((size_t)p.M * Co * es(dtype)); p.ldo = Co; p.epi = EPI_STORE;
+  }
   return launch_igemm(p, dtype, s);
 }
 

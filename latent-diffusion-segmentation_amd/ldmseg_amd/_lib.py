@@ -27,6 +27,10 @@ class VAECfg(C.Structure):
                 ("block_out_channels", C.c_int32 * 4), ("compute_dtype", C.c_int32), ("device", C.c_int32)]
 
 
+class VAEImageCfg(C.Structure):
+    _fields_ = [("compute_dtype", C.c_int32), ("device", C.c_int32)]
+
+
 class SampleCfg(C.Structure):
     _fields_ = [("n_steps", C.c_int32), ("timesteps", C.POINTER(C.c_int64)), ("coef", C.POINTER(C.c_float)),
                 ("prediction_type", C.c_int32), ("clip_sample", C.c_int32), ("self_condition", C.c_int32),
@@ -56,6 +60,10 @@ SIGNATURES = {
     "ldmseg_add_noise": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _i, _sz, _vp]),
     "ldmseg_remove_noise": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _i, _sz, _vp]),
     "ldmseg_sample_loop": (_i, [_vp, C.POINTER(SampleCfg), _vp, _vp, _i, _i, _vp, _vp]),
+    "ldmseg_vae_image_create": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
+    "ldmseg_vae_image_destroy": (None, [_vp]),
+    "ldmseg_vae_image_num_params": (_i64, [_vp]),
+    "ldmseg_vae_image_encode": (_i, [_vp, _vp, _f, _f, _i, _i, _i, _vp, _vp]),
     "ldmseg_panoptic_postprocess": (_i, [_vp, _i, _i, _i, _i, _i, _i, _f, _i, _d, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ldmseg_bit_encode": (_i, [_vp, _i, _i, _i, _i64, _f, _f, _f, _vp, _vp, _vp]),
     "ldmseg_bit_decode": (_i, [_vp, _i, _i, _i, _vp, _vp]),

@@ -1,2 +1,2 @@
 from .unet import UNet  # noqa: F401
-from .vae import GeneralVAESeg, DiagonalGaussianDistribution  # noqa: F401
+from .vae import GeneralVAESeg, GeneralVAEImage, DiagonalGaussianDistribution  # noqa: F401

@@ -172,3 +172,83 @@ class GeneralVAESeg(object):
         return VAEOutput(sample=dec, posterior=posterior)
 
     __call__ = forward
+
+
+
+class GeneralVAEImage(object):
+    """ldmseg/models/vae.py:36-39 `GeneralVAEImage(AutoencoderKL)` with the decoder removed (tools/main_ldm.py:137-139):
+    the RGB encoder used as `encode_func` in `TrainerDiffusion.encode_inputs` (trainers_ldm_cond.py:360-375).
+
+    state_dict: `AutoencoderKL.state_dict()` / the 'vae_image' entry of ldmseg.pt (decoder keys are ignored).
+    """
+
+    def __init__(self, state_dict, scaling_factor: float = 0.18215, device: Union[str, torch.device] = "cuda:0",
+                 compute_dtype="bf16", **unused):
+        from ..weights import vae_image_schema
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("GeneralVAEImage needs an MI355X device (no CPU fallback)")
+        self.scaling_factor = scaling_factor
+        self.dtype = torch.float32
+        old = "encoder.mid_block.attentions.0.query.weight" in state_dict
+        schema = vae_image_schema(old_attention_names=old)
+        missing = [k for k in schema if k not in state_dict]
+        if missing:
+            raise KeyError(f"state dict lacks AutoencoderKL encoder tensors, e.g. {missing[:3]}")
+        sd = {}
+        for k in schema:
+            t = state_dict[k]
+            # newer diffusers store the attention projections as 1x1 convs or Linear; both flatten to [512, 512]
+            sd[k] = t.reshape(schema[k]) if tuple(t.shape) != tuple(schema[k]) else t
+        cd = {"bf16": _lib.BF16, torch.bfloat16: _lib.BF16, "fp32": _lib.F32, torch.float32: _lib.F32,
+              "float32": _lib.F32, "bfloat16": _lib.BF16}[compute_dtype]
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        cfg = _lib.VAEImageCfg(cd, idx)
+        n, names, ptrs, numels, keep = _lib.weight_arrays(sd, self.device)
+        handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            torch.cuda.synchronize(self.device)
+            _lib.check(_lib.lib().ldmseg_vae_image_create(C.byref(cfg), n, names, ptrs, numels, C.byref(handle)),
+                       "ldmseg_vae_image_create")
+        del keep
+        self._h = handle
+
+    def set_scaling_factor(self, scaling_factor):          # vae.py:38-39
+        self.scaling_factor = scaling_factor
+
+    @property
+    def num_parameters(self) -> int:
+        return int(_lib.lib().ldmseg_vae_image_num_params(self._h))
+
+    def eval(self):
+        return self
+
+    def to(self, *_a, **_k):
+        return self
+
+    def requires_grad_(self, *_a, **_k):
+        return self
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                _lib.lib().ldmseg_vae_image_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    def encode_moments(self, images: torch.Tensor, in_mul: float = 1.0, in_add: float = 0.0) -> torch.Tensor:
+        x = _lib.require_cuda_f32(images, "images")
+        B, Cin, H, W = x.shape
+        if Cin != 3 or H % 8 or W % 8:
+            raise ValueError(f"expected [B,3,H,W] with H, W multiples of 8, got {tuple(x.shape)}")
+        mom = torch.empty((B, 8, H // 8, W // 8), device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().ldmseg_vae_image_encode(self._h, _lib.ptr(x), in_mul, in_add, B, H, W, _lib.ptr(mom),
+                                                          _lib.stream_ptr(x.device)), "ldmseg_vae_image_encode")
+        return mom
+
+    def encode(self, x: torch.Tensor) -> EncoderOutput:
+        """AutoencoderKL.encode(x).latent_dist (.mode() / .sample())."""
+        return EncoderOutput(latent_dist=DiagonalGaussianDistribution(self.encode_moments(x)))

@@ -27,7 +27,8 @@ from .. import _lib
 
 class TrainerDiffusion(object):
     def __init__(self, vae_semseg, unet, noise_scheduler, self_condition: Optional[bool] = None,
-                 device=None, latent_size: int = 64):
+                 device=None, latent_size: int = 64, vae_image=None):
+        self.vae_image = vae_image            # RGB encoder (trainers_ldm_cond.py:58,111); optional here
         self.vae_semseg = vae_semseg
         self.unet_model = unet
         self.noise_scheduler = noise_scheduler
@@ -253,13 +254,31 @@ class TrainerDiffusion(object):
 
     @torch.no_grad()
     def encode_inputs(self, images: torch.Tensor, sample_posterior: bool = False, encode_func=None,
-                      scaling_factor: Optional[float] = None, generator=None):
-        """Segmentation side of :335-394: bit maps in [0,1] -> 2x-1 -> seg-VAE -> latents * scaling."""
-        if scaling_factor is None:
-            scaling_factor = self.vae_semseg.scaling_factor
-        mom = self.vae_semseg.encode_moments(images, in_mul=2.0, in_add=-1.0)      # images = 2*images - 1 (:369)
+                      scaling_factor: Optional[float] = None, resize: Optional[int] = None, weight_dtype=None,
+                      generator=None):
+        """:335-394.  images in [0,1] (RGB, or bit maps for the segmentation VAE) -> 2x-1 -> encoder ->
+        (latents, latents_mean) * scaling_factor.  As in the reference the default encoder is the image VAE
+        (`self.vae_image.encode`); pass `encode_func=self.vae_semseg.encode` with its scaling factor for
+        segmentation maps.  The 2x-1 is fused into the encoder's input packing."""
+        import torch.nn.functional as F
         from ..models.vae import DiagonalGaussianDistribution
-        dist_ = DiagonalGaussianDistribution(mom)
+        if encode_func is None:
+            if self.vae_image is None:
+                raise ValueError("no encode_func given and the trainer was built without vae_image")
+            encode_func = self.vae_image.encode
+        owner = getattr(encode_func, "__self__", None)
+        if scaling_factor is None:
+            scaling_factor = (self.vae_image if self.vae_image is not None else owner).scaling_factor
+        if resize is not None:
+            images = F.interpolate(images, size=(resize, resize), mode='bilinear', align_corners=False)
+        if owner is not None and hasattr(owner, "encode_moments"):
+            dist_ = DiagonalGaussianDistribution(owner.encode_moments(images, in_mul=2.0, in_add=-1.0))   # :369 fused
+        else:
+            dist_ = encode_func(2. * images - 1.).latent_dist
         mean = dist_.mode()
         latents = dist_.sample(generator) if sample_posterior else mean.clone()
+        if resize is not None:
+            size = (self.latent_size, self.latent_size)
+            latents = F.interpolate(latents, size=size, mode='bilinear', align_corners=False)
+            mean = F.interpolate(mean, size=size, mode='bilinear', align_corners=False)
         return latents * scaling_factor, mean * scaling_factor

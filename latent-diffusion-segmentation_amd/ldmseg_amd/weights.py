@@ -149,6 +149,53 @@ def vae_schema(in_channels=7, int_channels=256, out_channels=128,
     return sd
 
 
+def vae_image_schema(old_attention_names=True):
+    """Ordered key -> shape of the encoder half of the SD-1.x AutoencoderKL (GeneralVAEImage with the decoder
+    removed, tools/main_ldm.py:137-139) + quant_conv.  diffusers 0.16.1 names the attention projections
+    query/key/value/proj_attn; later releases to_q/to_k/to_v/to_out.0."""
+    sd = OrderedDict()
+
+    def conv(name, co, ci, k=3):
+        sd[name + ".weight"] = (co, ci, k, k)
+        sd[name + ".bias"] = (co,)
+
+    def norm(name, c):
+        sd[name + ".weight"] = (c,)
+        sd[name + ".bias"] = (c,)
+
+    def resnet(p, ci, co):
+        norm(p + "norm1", ci)
+        conv(p + "conv1", co, ci)
+        norm(p + "norm2", co)
+        conv(p + "conv2", co, co)
+        if ci != co:
+            conv(p + "conv_shortcut", co, ci, 1)
+
+    ch = (128, 256, 512, 512)
+    conv("encoder.conv_in", ch[0], 3)
+    cin = ch[0]
+    for i, co in enumerate(ch):
+        for j in range(2):
+            resnet(f"encoder.down_blocks.{i}.resnets.{j}.", cin, co)
+            cin = co
+        if i < 3:
+            conv(f"encoder.down_blocks.{i}.downsamplers.0.conv", co, co)
+    resnet("encoder.mid_block.resnets.0.", 512, 512)
+    ap = "encoder.mid_block.attentions.0."
+    norm(ap + "group_norm", 512)
+    for nm in (("query", "key", "value", "proj_attn") if old_attention_names else ("to_q", "to_k", "to_v", "to_out.0")):
+        sd[ap + nm + ".weight"] = (512, 512)
+        sd[ap + nm + ".bias"] = (512,)
+    resnet("encoder.mid_block.resnets.1.", 512, 512)
+    norm("encoder.conv_norm_out", 512)
+    conv("encoder.conv_out", 8, 512)
+    conv("quant_conv", 8, 8, 1)
+    return sd
+
+
+VAE_IMAGE_NORM_KEYS = ("encoder.mid_block.attentions.0.group_norm.weight", "encoder.mid_block.attentions.0.group_norm.bias")
+
+
 def count_params(schema):
     n = 0
     for shp in schema.values():
