@@ -56,7 +56,9 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
 __device__ __forceinline__ void glds16_sbase(unsigned voff, const void* sbase, unsigned lds_dst) {
   asm volatile(
       "s_mov_b32 m0, %2\n\t"
-      "s_nop 0\n\t"
+      "s_nop 3\n\t"   // M0 write -> LDS-DMA needs 1 wait state; an SGPR base written by SALU / v_readfirstlane needs 5
+                       // before a VMEM instruction reads it, and the hazard recognizer does not look inside inline asm
+                       // (a register-load variant of this helper went to wild addresses without them)
       "global_load_lds_dwordx4 %0, %1"
       :
       : "v"(voff), "s"(sbase), "s"(lds_dst)
