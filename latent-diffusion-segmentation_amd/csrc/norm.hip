@@ -27,6 +27,33 @@ __device__ __forceinline__ uint4 load_cat(const GNParams& p, int b, int pix, int
   return *(const uint4*)((const T*)p.src1 + ((size_t)b * p.HW + pix) * p.C1 + (c - p.C0));
 }
 
+// fixed-order reduction of one image's per-chunk partials: 8 lanes per group (each a fixed chunk subset, fixed
+// shuffle tree -> deterministic), fp64 for the final mean / variance.  256 threads; out = {mean, rstd} per group.
+__device__ __forceinline__ void gn_reduce_stats(const GNParams& p, int b, int cpg, float* out) {
+  const int g = threadIdx.x >> 3, sub = threadIdx.x & 7;
+  double s = 0.0, q = 0.0;
+  if (g < p.groups) {
+    for (int ch = sub; ch < p.nchunk; ch += 8) {
+      const float2 pp = *(const float2*)(p.partial + (((size_t)b * p.nchunk + ch) * p.groups + g) * 2);
+      s += (double)pp.x;
+      q += (double)pp.y;
+    }
+  }
+#pragma unroll
+  for (int o = 4; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o);
+    q += __shfl_xor(q, o);
+  }
+  if (g < p.groups && sub == 0) {
+    const double n = (double)p.HW * cpg;
+    const double mean = s / n;
+    double var = q / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    out[g * 2 + 0] = (float)mean;
+    out[g * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.eps));
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void gn_partial_kernel(const GNParams p) {
   constexpr int PC = Chunk<T>::N;
@@ -52,7 +79,24 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const GNParams p) {
       const int c0 = v * PC;
       const int g0 = c0 / cpg;
       const int split = min(PC, (g0 + 1) * cpg - c0);  // elements [0,split) -> g0, rest -> g0+1
-      for (int pix = p0 + ty; pix < p1; pix += TY) {
+      // four pixels per trip: the loads are issued together, so each thread keeps 64 B in flight
+      int pix = p0 + ty;
+      for (; pix + 3 * TY < p1; pix += 4 * TY) {
+        uint4 raw[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) raw[u] = load_cat<T>(p, b, pix + u * TY, v);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          float f[PC];
+          Chunk<T>::unpack(raw[u], f);
+#pragma unroll
+          for (int e = 0; e < PC; ++e) {
+            if (e < split) { s0 += f[e]; q0 += f[e] * f[e]; }
+            else { s1 += f[e]; q1 += f[e] * f[e]; }
+          }
+        }
+      }
+      for (; pix < p1; pix += TY) {
         const uint4 raw = load_cat<T>(p, b, pix, v);
         float f[PC];
         Chunk<T>::unpack(raw, f);
@@ -94,33 +138,11 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GNParams p) {
   const int cpg = C / p.groups;
   const int nvec = C / PC;
   const int b = blockIdx.y;
-  __shared__ float s_mean[64], s_rstd[64];
-  {
-    // combine the per-chunk partials: 8 lanes per group (fixed chunk order per lane, fixed
-    // shuffle tree -> deterministic), fp64 for the final mean/variance
-    const int g = threadIdx.x >> 3, sub = threadIdx.x & 7;
-    double s = 0.0, q = 0.0;
-    if (g < p.groups) {
-      for (int ch = sub; ch < p.nchunk; ch += 8) {
-        const float2 pp = *(const float2*)(p.partial + (((size_t)b * p.nchunk + ch) * p.groups + g) * 2);
-        s += (double)pp.x;
-        q += (double)pp.y;
-      }
-    }
-#pragma unroll
-    for (int o = 4; o > 0; o >>= 1) {
-      s += __shfl_xor(s, o);
-      q += __shfl_xor(q, o);
-    }
-    if (g < p.groups && sub == 0) {
-      const double n = (double)p.HW * cpg;
-      const double mean = s / n;
-      double var = q / n - mean * mean;
-      if (var < 0.0) var = 0.0;
-      s_mean[g] = (float)mean;
-      s_rstd[g] = (float)(1.0 / sqrt(var + (double)p.eps));
-    }
-  }
+  __shared__ float s_stat[64][2];
+  // every apply workgroup reduces the image's partials itself.  (Having the last-finishing partial workgroup finalise
+  // (mean, rstd) behind a ticket needs agent-scope fences, which on this 8-XCD part write back / invalidate whole
+  // L2s: measured 2.4x slower for the GroupNorm family.)
+  gn_reduce_stats(p, b, cpg, &s_stat[0][0]);
   __syncthreads();
   // every thread owns fixed channel vectors, so the per-channel affine (x*a + b with
   // a = rstd*gamma, b = beta - mean*a) is computed once and the pixel loop is one FMA per element
@@ -139,8 +161,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GNParams p) {
     for (int e = 0; e < PC; ++e) {
       const int c = c0 + e;
       const int g = c / cpg;
-      a[e] = s_rstd[g] * p.gamma[c];
-      bb[e] = p.beta[c] - s_mean[g] * a[e];
+      a[e] = s_stat[g][1] * p.gamma[c];
+      bb[e] = p.beta[c] - s_stat[g][0] * a[e];
     }
     const T* src;
     int cs, coff;
@@ -148,7 +170,25 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GNParams p) {
     else { src = (const T*)p.src1; cs = p.C1; coff = c0 - p.C0; }
     src += (size_t)b * p.HW * cs + coff;
     T* dst = (T*)p.out + (size_t)b * p.HW * C + c0;
-    for (int pix = p0 + ty; pix < p1; pix += TY) {
+    int pix = p0 + ty;
+    for (; pix + 3 * TY < p1; pix += 4 * TY) {          // four independent 16-B loads in flight per thread
+      uint4 raw[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) raw[u] = *(const uint4*)(src + (size_t)(pix + u * TY) * cs);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float f[PC];
+        Chunk<T>::unpack(raw[u], f);
+#pragma unroll
+        for (int e = 0; e < PC; ++e) {
+          float y = f[e] * a[e] + bb[e];
+          if (p.silu) y = silu_f(y);
+          f[e] = y;
+        }
+        *(uint4*)(dst + (size_t)(pix + u * TY) * C) = Chunk<T>::pack(f);
+      }
+    }
+    for (; pix < p1; pix += TY) {
       float f[PC];
       Chunk<T>::unpack(*(const uint4*)(src + (size_t)pix * cs), f);
 #pragma unroll
@@ -318,8 +358,12 @@ int run_gn(const GNParams& p, hipStream_t s) {
   // pixel chunks: >= 4 pixels per thread row, ~2048 workgroups in total
   const int nvec = C / PC;
   const int ty = 256 / (nvec < 256 ? nvec : 256);
-  int blocks = (p.HW + 4 * ty - 1) / (4 * ty);
-  const int cap = max(1, 2048 / p.B);
+  // 16 pixels per thread row (4 unrolled trips) on the big maps, down to 4 when that would leave fewer than ~512
+  // workgroups on the chip (every workgroup re-reduces the image's partials first, so fewer and fatter is better)
+  int blocks = (p.HW + 16 * ty - 1) / (16 * ty);
+  const int want = max(1, 512 / p.B);
+  if (blocks < want) blocks = min(want, (p.HW + 4 * ty - 1) / (4 * ty));
+  const int cap = max(1, 1024 / p.B);
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(gn_apply_kernel<T>, dim3(blocks, p.B), dim3(256), 0, s, p);
