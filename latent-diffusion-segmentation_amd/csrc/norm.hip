@@ -335,6 +335,92 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const GNParams p) {
   }
 }
 
+// Feature maps up to 32x32: one workgroup per (image, block of GB = 1 or 2 groups whose channels make whole 16-byte
+// vectors), the block's HW x GB*cpg elements held in registers as 16-byte vectors: statistics, normalisation and the
+// store in ONE launch that reads the tensor once (the two-launch path reads it twice and pays two dependent launches;
+// at these sizes - 0.3 to 5 MB - that is most of its time).  Thread t owns vector j = t % vpp of pixels t / vpp + PPI*k,
+// so its channels, groups and gamma/beta are fixed and all MAXV loads are issued before the first use.
+template <typename T, int MAXV>
+__global__ __launch_bounds__(256) void gn_fused_kernel(const GNParams p, int GB) {
+  constexpr int PC = Chunk<T>::N;
+  const int C = p.C0 + p.C1;
+  const int cpg = C / p.groups;
+  const int vpp = GB * cpg / PC;                    // vectors per pixel of this group block
+  const int ppi = 256 / vpp;                        // pixels per trip
+  const int b = blockIdx.y;
+  const int cfirst = blockIdx.x * GB * cpg;
+  const int tid = threadIdx.x;
+  const int j = tid % vpp, pr = tid / vpp;
+  const bool active = pr < ppi;
+  const int c0 = cfirst + j * PC;                   // first channel of this thread's vector
+  const int glo = (j * PC) / cpg;                   // 0 or 1: block-local group of its first element
+  const int split = min(PC, (glo + 1) * cpg - j * PC);   // elements [0,split) -> glo, the rest -> glo+1
+  const T* src;
+  int cs;
+  if (c0 < p.C0) { src = (const T*)p.src0 + (size_t)b * p.HW * p.C0 + c0; cs = p.C0; }
+  else { src = (const T*)p.src1 + (size_t)b * p.HW * p.C1 + (c0 - p.C0); cs = p.C1; }
+  u32x4 raw[MAXV];
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    const int pix = pr + ppi * k;
+    raw[k] = (active && pix < p.HW) ? *(const u32x4*)(src + (size_t)pix * cs) : u32x4{0u, 0u, 0u, 0u};
+  }
+  float slo = 0.f, qlo = 0.f, shi = 0.f, qhi = 0.f;
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+#pragma unroll
+    for (int e = 0; e < PC; ++e) {
+      const float f = to_f32<T>(chunk_elem<T>(raw[k], e));     // out-of-range vectors are zero: they add nothing
+      if (e < split) { slo += f; qlo += f * f; }
+      else { shi += f; qhi += f * f; }
+    }
+  }
+  // block-local group sums: group 0 gets the low part of glo == 0 vectors, group 1 the rest
+  float v[4] = {glo == 0 ? slo : 0.f, glo == 0 ? qlo : 0.f, glo == 0 ? shi : slo, glo == 0 ? qhi : qlo};
+  __shared__ float red[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v[i] = wave64_sum(v[i]);
+    if ((tid & 63) == 0) red[i][tid >> 6] = v[i];
+  }
+  __syncthreads();
+  const double n = (double)p.HW * cpg;
+  float mean[2], rstd[2];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const double st = (double)red[2 * g][0] + (double)red[2 * g][1] + (double)red[2 * g][2] + (double)red[2 * g][3];
+    const double qt = (double)red[2 * g + 1][0] + (double)red[2 * g + 1][1] + (double)red[2 * g + 1][2] + (double)red[2 * g + 1][3];
+    const double m = st / n;
+    double var = qt / n - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[g] = (float)m;
+    rstd[g] = (float)(1.0 / sqrt(var + (double)p.eps));
+  }
+  if (!active) return;
+  float a[PC], bb[PC];
+#pragma unroll
+  for (int e = 0; e < PC; ++e) {
+    const int g = (e < split) ? glo : glo + 1;
+    a[e] = (g == 0 ? rstd[0] : rstd[1]) * p.gamma[c0 + e];
+    bb[e] = p.beta[c0 + e] - (g == 0 ? mean[0] : mean[1]) * a[e];
+  }
+  T* dst = (T*)p.out + (size_t)b * p.HW * C + c0;
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    const int pix = pr + ppi * k;
+    if (pix < p.HW) {
+      float f[PC];
+#pragma unroll
+      for (int e = 0; e < PC; ++e) {
+        float y = to_f32<T>(chunk_elem<T>(raw[k], e)) * a[e] + bb[e];
+        if (p.silu) y = silu_f(y);
+        f[e] = y;
+      }
+      *(uint4*)(dst + (size_t)pix * C) = Chunk<T>::pack(f);
+    }
+  }
+}
+
 template <typename T>
 int run_gn(const GNParams& p, hipStream_t s) {
   constexpr int PC = Chunk<T>::N;
@@ -344,6 +430,22 @@ int run_gn(const GNParams& p, hipStream_t s) {
   // (128 channels in bf16: cpg 4, PC 8 - the image VAE's first level)
   if (C / p.groups < PC && 2 * (C / p.groups) != PC) return -2;
   if (C / PC > 256 * kMaxIter) return -2;
+  {
+    // single-launch register-resident kernel: GB = 1 or 2 groups per workgroup forming whole 16-byte vectors
+    constexpr int MAXV = 22;
+    const int cpg = C / p.groups;
+    for (int GB = 1; GB <= 2; ++GB) {
+      if ((GB * cpg) % PC != 0 || p.groups % GB != 0) continue;
+      const int vpp = GB * cpg / PC;
+      if (vpp > 64) continue;
+      const int ppi = 256 / vpp;
+      if ((p.HW + ppi - 1) / ppi > MAXV) continue;
+      if ((long)p.B * (p.groups / GB) < 96) continue;          // too few workgroups to fill the chip
+      if (p.HW <= 64 && vpp < 10) continue;                    // 8x8 maps with short runs: gn_small measured faster (8.0 vs 9.7 us)
+      hipLaunchKernelGGL((gn_fused_kernel<T, MAXV>), dim3(p.groups / GB, p.B), dim3(256), 0, s, p, GB);
+      return hipGetLastError() == hipSuccess ? 0 : -3;
+    }
+  }
   {
     constexpr int EPU = 4 / (int)sizeof(T);
     const int cpg = C / p.groups;

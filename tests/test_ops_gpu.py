@@ -121,6 +121,12 @@ def test_linear(L, dt, case):
     (3, 256, 0, 1024, 1e-6, 1),       # seg-VAE GN (cpg = 8)
     (1, 2560, 0, 4, 1e-5, 0),         # 2x2 map, widest concat
     (2, 1280, 0, 1, 1e-6, 0),         # single pixel
+    # enough (image, group block) workgroups for the single-launch register-resident kernel:
+    (8, 1280, 0, 256, 1e-5, 1),       # one group per workgroup (80-B runs in bf16)
+    (8, 640, 0, 1024, 1e-5, 1),       # two groups per workgroup in bf16, 21 vectors per thread
+    (8, 1280, 640, 256, 1e-5, 1),     # concat, cpg = 60: group pairs straddle the source boundary
+    (4, 2560, 0, 64, 1e-6, 0),
+    (8, 256, 0, 100, 1e-6, 1),        # one vector per pixel, ragged pixel count
 ])
 def test_groupnorm(L, dt, case):
     B, Cc, C2, HW, eps, silu = case
