@@ -191,6 +191,28 @@ def test_attention(L, dt, B, N, Cc):
 
 
 @pytest.mark.parametrize("dt", [F32, BF16])
+def test_attention_long_context(L, dt):
+    """N = 16384 tokens (128x128 latents, BASELINE's 1024x1024 config): 512 sampled query rows against all keys."""
+    B, N, Cc, d = 1, 16384, 320, 40
+    g = torch.Generator().manual_seed(17)
+    qkv = torch.randn(B, N, 3 * Cc, generator=g)
+    qkv[:, :, :Cc] *= 1.5
+    src = bf16_round(qkv) if dt == BF16 else qkv
+    rows = torch.randperm(N, generator=g)[:512]
+    q, k, v = src.chunk(3, -1)
+    qs = q[0, rows].view(512, 8, d).transpose(0, 1).double()           # [8, 512, d]
+    kk = k[0].view(N, 8, d).transpose(0, 1).double()
+    vv = v[0].view(N, 8, d).transpose(0, 1).double()
+    ref = (torch.softmax(qs @ kk.transpose(-1, -2) * d ** -0.5, -1) @ vv).transpose(0, 1).reshape(512, Cc).float()
+    out = torch.empty(B, N, Cc, device="cuda")
+    dq = dev(qkv)
+    assert L.lib().ldmseg_op_attention(P(dq), B, N, Cc, 8, dt, P(out), None) == 0
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    assert rel_err(out[0].cpu()[rows], ref) < (1.5e-2 if dt == BF16 else 2e-5)
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
 def test_convt2_and_bilinear(L, dt):
     g = torch.Generator().manual_seed(5)
     x = torch.randn(2, 256, 6, 6, generator=g)

@@ -236,6 +236,37 @@ def test_full_size_properties(unets):
     assert torch.equal(u(x, tt).sample, y1)                         # [B] timesteps == broadcast scalar
 
 
+def test_config_inpaint_b16_properties(unets, sched_kw):
+    """BASELINE inpainting config (B=16, L=64, 50 % known latents), bf16: known region exact, deterministic."""
+    from ldmseg_amd.schedulers import DDIMNoiseScheduler
+    from ldmseg_amd.trainers import TrainerDiffusion
+    tr = TrainerDiffusion(None, unets["bf16"], DDIMNoiseScheduler(**sched_kw))
+    g = torch.Generator().manual_seed(7)
+    rgb = (0.18215 * torch.randn(16, 4, 64, 64, generator=g)).to(DEV)
+    z0 = (0.2 * torch.randn(16, 4, 64, 64, generator=g)).to(DEV)
+    known = (torch.rand(16, 1, 64, 64, generator=g) < 0.5).to(DEV)
+    a = tr.sample_inpaint([""] * 16, known, z0, num_inference_steps=6, seed=42, rgb_latents=rgb)
+    b = tr.sample_inpaint([""] * 16, known, z0, num_inference_steps=6, seed=42, rgb_latents=rgb)
+    assert a.shape == (16, 4, 64, 64) and torch.isfinite(a).all() and torch.equal(a, b)
+    m = known.expand_as(z0)
+    assert torch.equal(a[m], z0[m])
+    assert 0.45 < m.float().mean().item() < 0.55
+
+
+def test_config_l128_b4_properties(unets):
+    """BASELINE 1024x1024 config (B=4, 128x128x4 latents, N = 16384 tokens in the first attention level), bf16."""
+    u = unets["bf16"]
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(4, 12, 128, 128, generator=g).to(DEV)
+    t = torch.tensor(259, device=DEV)
+    y1 = u(x, t).sample
+    assert y1.shape == (4, 4, 128, 128) and torch.isfinite(y1).all()
+    assert torch.equal(u(x, t).sample, y1)
+    perm = torch.tensor([2, 0, 3, 1], device=DEV)
+    assert rel_err(u(x[perm].contiguous(), t).sample, y1[perm]) < 1e-6
+    assert rel_err(u(x[1:2].contiguous(), t).sample, y1[1:2]) < 2e-2
+
+
 # ------------------------------------------------------------------ section 8(f) rank 3: bit codec + checkpoint readers
 def test_bitcodec_bit_exact_vs_reference_golden(golden):
     from ldmseg_amd.data import encode_bitmap, decode_bitmap
