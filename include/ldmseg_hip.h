@@ -223,7 +223,9 @@ int ldmseg_profile_read(int family, int64_t* launches, double* total_ms, double*
 int ldmseg_profile_reset(void);
 /* one CSV line per recorded launch (family,label,ms,flops); label carries the launch shape */
 int ldmseg_profile_dump(const char* path);
-/* tuning knobs for experiments; key 0 = igemm K-loop ring depth (2 | 3 | 4) */
+/* measurement knobs (defaults = the shipped configuration): key 1 = igemm tile-policy bits in value[8..12] (and, in
+ * -DLDMSEG_IGEMM_ABLATE builds only, phase-ablation flags in value[0..7]); key 2 = attention query-tile choice;
+ * keys 3/4 = low/high half of a device buffer for per-workgroup s_memtime stamps (ablate builds). */
 int ldmseg_debug_set(int key, int value);
 
 #ifdef __cplusplus

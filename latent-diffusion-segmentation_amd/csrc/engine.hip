@@ -1340,7 +1340,6 @@ int ldmseg_profile_read(int family, int64_t* launches, double* total_ms, double*
 
 // tuning knobs for experiments: key 0 = igemm K-loop ring depth (2, 3, 4)
 int ldmseg_debug_set(int key, int value) {
-  if (key == 0) { igemm_set_nbuf(value); return 0; }
   if (key == 2) { attention_set_qf1(value); return 0; }
   if (key == 1) { igemm_set_dbg(value); return 0; }   // bits 0-7 ablation flags (LDMSEG_IGEMM_ABLATE builds), bits 8-12 tile policy
   static unsigned long long ts_ptr = 0;                // keys 3/4: low/high half of a device stamp buffer (ablate builds)

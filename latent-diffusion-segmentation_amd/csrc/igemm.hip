@@ -799,7 +799,6 @@ int dispatch(const IgemmParams& p, hipStream_t s) {
 
 }  // namespace
 
-void igemm_set_nbuf(int) {}
 void igemm_set_tsbuf(void* b) { g_tsbuf = b; }
 void igemm_set_dbg(int f) { g_dbg = f & 0xff; g_big = (f >> 8) & 31; }   // bits 8-12 select the tile policy
 

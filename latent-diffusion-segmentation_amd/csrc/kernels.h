@@ -55,7 +55,6 @@ int launch_igemm(const IgemmParams& p, int dtype, hipStream_t s);
 size_t igemm_partial_bytes(const IgemmParams& p);
 int igemm_plan_splits(const IgemmParams& p, int dtype);
 void attention_set_qf1(int v);    // tuning knob: force 16 query rows per wave
-void igemm_set_nbuf(int n);
 void igemm_set_tsbuf(void* dev_buf);   // LDMSEG_IGEMM_ABLATE builds only
 void igemm_set_dbg(int flags);   // ablation flags (profiling only)   // K-loop ring depth (2, 3, 4) - tuning knob
 // tile the launcher would pick (for weight padding): N tile size for a given N.
