@@ -199,6 +199,34 @@ def test_sample_vs_oracle(unets, unet_sd, sched_kw):
     assert rel_err(out, ref) < 2e-3
 
 
+def test_unet_8ch_variant_without_self_conditioning(sched_kw):
+    """UNet.modify_encoder's 8-channel conv_in (no self-conditioning channel, unet.py:178-233): forward and the
+    sampling loop against the oracle."""
+    from ldmseg_amd import weights
+    from ldmseg_amd.models import UNet
+    from ldmseg_amd.schedulers import DDIMNoiseScheduler
+    from ldmseg_amd.trainers import TrainerDiffusion
+    sd8 = weights.generate(weights.unet_schema(8, False), seed=0)
+    u8 = UNet(sd8, in_channels=8, device=DEV, compute_dtype="fp32")
+    assert u8.num_parameters == weights.count_params(weights.unet_schema(8, False))
+    x = torch.randn(2, 8, 16, 16, generator=torch.Generator().manual_seed(3))
+    t = torch.tensor([999, 19])
+    with torch.no_grad():
+        ref = o_unet.unet_forward(sd8, x, t)
+    assert rel_err(u8(x.to(DEV), t.to(DEV)).sample, ref) <= 1e-3
+    tr = TrainerDiffusion(None, u8, DDIMNoiseScheduler(**sched_kw))
+    assert tr.self_condition is False
+    rgb = 0.18215 * torch.randn(1, 4, 16, 16, generator=torch.Generator().manual_seed(1234))
+    out = tr.sample([""], num_inference_steps=3, seed=42, rgb_latents=rgb.to(DEV))
+    so = o_ddim.OracleDDIM(**sched_kw)
+    so.set_timesteps_inference(3)
+    with torch.no_grad():
+        ref = o_sample.sample(lambda inp, tt: o_unet.unet_forward(sd8, inp, tt), so, rgb, seed=42, self_condition=False)
+    assert rel_err(out, ref) < 2e-3
+    with pytest.raises(Exception):
+        u8(torch.randn(1, 12, 16, 16, device=DEV), torch.tensor(5, device=DEV))     # wrong channel count is an error
+
+
 def test_inpaint_vs_oracle(unets, unet_sd, sched_kw):
     from ldmseg_amd.schedulers import DDIMNoiseScheduler
     from ldmseg_amd.trainers import TrainerDiffusion
