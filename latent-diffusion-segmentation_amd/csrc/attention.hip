@@ -113,6 +113,18 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
   ATTN_PREFETCH(0, kregA, vregA)
   // zero the whole LDS once: K pad chunks (d >= D), V^T rows d >= D and row pads stay zero
   for (int i = tid * 16; i < NST * STAGE; i += 256 * 16) *(uint4*)(smem + i) = make_uint4(0, 0, 0, 0);
+  // ONES: the head dim leaves spare rows in the last 16-row fragment of V^T (d = 40 -> rows 40..47).  Row D holds
+  // ones, so the PV matrix product accumulates the softmax denominator sum_k p[q][k] into O^T[D][q] for free -
+  // rescaled together with O - and the per-score row-sum adds disappear from the VALU-bound softmax.
+  // (bf16 mode only: the fp32 parity mode keeps the exact VALU row sums)
+  constexpr bool ONES = (D % 16) != 0 && sizeof(T) == 2;
+  if constexpr (ONES) {
+    __syncthreads();
+    if (tid < NST * BKV) {
+      const int st = tid / BKV, key = tid % BKV;
+      *(T*)(smem + st * STAGE + Cfg::KS_BYTES + D * Cfg::VROW + key * sizeof(T)) = from_f32<T>(1.0f);
+    }
+  }
 
   // Q fragments (MFMA B operand): lane (q = lq, g = lg) holds chunk kg*4+g of its row
   const int q0 = qb * 64 * QF + wave * 16 * QF;
@@ -213,9 +225,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
           const float z = s[a][f][r];
           const float pv = __builtin_amdgcn_exp2f(z - mnew);
           s[a][f][r] = pv;
-          ps += pv;
+          if constexpr (!ONES) ps += pv;
         }
-      lrow[a] = lrow[a] * alpha[a] + ps;
+      if constexpr (!ONES) lrow[a] = lrow[a] * alpha[a] + ps;
     }
     // rescale O only when some row's running max actually grew in this tile (alpha == 1 exactly
     // otherwise): after the first few tiles this skips the accumulator round trip entirely
@@ -288,7 +300,13 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
   // ---- normalise and store: lane (q, g) holds d = df*16 + 4g + r ----
 #pragma unroll
   for (int a = 0; a < QF; ++a) {
-    const float l = xor32_sum(xor16_sum(lrow[a]));
+    float l;
+    if constexpr (ONES) {
+      // O^T[D][q] sits in lane (q, g = (D % 16) / 4), element (D % 16) % 4 of fragment D / 16
+      l = __shfl(o[a][D / 16][(D % 16) % 4], lq + 16 * ((D % 16) / 4), 64);
+    } else {
+      l = xor32_sum(xor16_sum(lrow[a]));
+    }
     const float inv = 1.0f / l;
     const int q = q0 + a * 16 + lq;
     if (q >= N) continue;
