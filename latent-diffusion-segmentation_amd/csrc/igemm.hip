@@ -109,10 +109,15 @@ constexpr bool epi_stage_dedicated() { return epi_stage_bytes<BM, BN, WAVES_M, W
 // Per K tile every wave: issues the DMA of stream position +NST-1 into the stage read one tile ago,
 // computes the current tile, waits with a COUNTED vmcnt until the next tile has landed (later ones
 // stay in flight) and passes the single barrier.
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int NST, bool PIPE>
-__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(const IgemmParams p) {   // <=256 regs: 2 workgroups/CU
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int NST, bool PIPE, int LDR>
+__global__ __launch_bounds__((WAVES_M * WAVES_N + LDR) * 64, 2) void igemm_kernel(const IgemmParams p) {   // <=256 regs: 2 waves/SIMD
   constexpr int NW = WAVES_M * WAVES_N;   // 4 waves (128-row tiles, 2 workgroups/CU) or 8 (256-row tiles)
   static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
+  // LDR > 0: producer / consumer split.  Waves NW..NW+LDR-1 only run the LDS-DMA stream (they sit blocked in the
+  // 64 B/clk DMA queue most of the time), waves 0..NW-1 only read fragments and issue MFMAs - so the matrix pipe of a
+  // SIMD is fed by a wave that never stalls on a DMA issue.  LDR == 0: every wave loads its share and computes.
+  constexpr int NLW = LDR ? LDR : NW;     // waves that run the DMA stream
+  static_assert(LDR == 0 || PIPE, "loader waves exist only in the pipelined loop");
   constexpr int BKE = kRowBytes / (int)sizeof(T);  // K elements per tile
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
   constexpr int MF = WTM / 16, NF = WTN / 16;
@@ -122,7 +127,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(const 
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool is_ldr = LDR ? wave_id >= NW : true;      // runs the DMA stream
+  const bool is_cmp = LDR ? wave_id < NW : true;       // reads fragments, MFMAs, epilogue
+  const int wave = LDR ? (wave_id < NW ? wave_id : wave_id - NW) : wave_id;   // index within its role
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
   // ---- work items: (m tile, n tile, K slice), n fastest.  Round j of this workgroup is item
@@ -154,11 +162,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(const 
   // group (1 KiB, lane l -> row l>>3, physical chunk l&7).  The XOR swizzle therefore lives on the
   // SOURCE side: the lane fetches logical chunk (l&7)^(row&7).  Rows 0..BM-1 of a stage are X,
   // rows BM.. are W; group g = i*NW + wave belongs to wave (g % NW).
-  constexpr int XG = BM / 8 / NW;              // X groups per wave per tile
+  constexpr int XG = BM / 8 / NLW;             // X groups per loading wave per tile
   constexpr int WGN = BN / 8;                  // W groups per tile
-  constexpr int WG = (WGN + NW - 1) / NW;      // W rounds; the last one may cover only waves < WREM
-  constexpr int WREM = WGN % NW;
-  static_assert(BM % (8 * NW) == 0 && BN % 8 == 0, "tile rows / loader mismatch");
+  constexpr int WG = (WGN + NLW - 1) / NLW;    // W rounds; the last one may cover only waves < WREM
+  constexpr int WREM = WGN % NLW;
+  static_assert(BM % (8 * NLW) == 0 && BN % 8 == 0, "tile rows / loader mismatch");
   const int ld_r = lane >> 3;                  // row within the 8-row group (== row & 7)
   const int ld_j = (lane & 7) ^ ld_r;          // logical 16-B chunk this lane fetches
   const bool w_last = (WREM == 0) || (wave < WREM);   // owns a group in the last W round (wave-uniform)
@@ -168,7 +176,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(const 
   unsigned woff[WG];                           // per-lane W row offsets relative to the item's W tile
 #pragma unroll
   for (int i = 0; i < WG; ++i)
-    woff[i] = (unsigned)(((size_t)((i * NW + wave) * 8 + ld_r) * K) * sizeof(T)) + (unsigned)ld_j * 16u;
+    woff[i] = (unsigned)(((size_t)((i * NLW + wave) * 8 + ld_r) * K) * sizeof(T)) + (unsigned)ld_j * 16u;
 
   auto item_range = [&](int item, int& m0, int& n0, int& z, int& kb, int& ke) __attribute__((always_inline)) {
     const int tile = item % ntiles;
@@ -195,7 +203,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(const 
     item_range(f_item, m0, n0, z, f_kt, f_kend);
 #pragma unroll
     for (int i = 0; i < XG; ++i) {
-      const int m = m0 + (i * NW + wave) * 8 + ld_r;
+      const int m = m0 + (i * NLW + wave) * 8 + ld_r;
       if (m < p.M) {
         const int b = m / HWo, rem = m - b * HWo;
         const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
@@ -247,7 +255,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(const 
     const unsigned dst = __builtin_amdgcn_readfirstlane(lds_wave + (unsigned)stage * (unsigned)kStageBytes);
 #pragma unroll
     for (int i = 0; i < XG; ++i) {
-      glds16(rowptr[i], dst + i * (NW * 1024));
+      glds16(rowptr[i], dst + i * (NLW * 1024));
       rowptr[i] += rowinc[i];
     }
     const unsigned long long wt_u = (unsigned long long)(uintptr_t)(wtile0 + (size_t)f_kt * kRowBytes);
@@ -257,7 +265,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(const 
     const unsigned wdst = dst + BM * kRowBytes;
 #pragma unroll
     for (int i = 0; i < WG; ++i)
-      if ((i + 1 < WG || w_last) && !DBG(p, 2)) glds16_sbase(woff[i], wt, wdst + i * (NW * 1024));
+      if ((i + 1 < WG || w_last) && !DBG(p, 2)) glds16_sbase(woff[i], wt, wdst + i * (NLW * 1024));
     ++f_kt;
     f_cc += BKE;
     if (f_cc == Ctot) { f_cc = 0; ++f_tap; }
@@ -555,15 +563,44 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(const 
     static_for<MF>([&](auto bi) __attribute__((always_inline)) { row_block(decltype(bi)::value, bi); });
   };
 
+  if constexpr (LDR > 0) {
+    if (!is_cmp) {
+      // ---- loader wave: nothing but the DMA stream, in step with the compute waves' barriers ----
+      item_setup();
+      int issued = 0;
+#pragma unroll
+      for (int j = 0; j < NST - 1; ++j)
+        if (fetch_next(j)) ++issued;
+      if (issued == NST - 1) wait_dma(std::integral_constant<int, NST - 2>{});
+      else wait_dma(std::integral_constant<int, 0>{});
+      __syncthreads();
+      int fstl = NST - 1;
+      for (int c_item = first_item; c_item < nwork; c_item += G) {
+        int m0c, n0c, zc, kb, ke;
+        item_range(c_item, m0c, n0c, zc, kb, ke);
+        for (int kt = kb; kt < ke; ++kt) {
+          const bool more = fetch_next(fstl);
+          if (more) wait_dma(std::integral_constant<int, NST - 2>{});
+          else wait_dma(std::integral_constant<int, 0>{});
+          __syncthreads();
+          fstl = (fstl + 1 == NST) ? 0 : fstl + 1;
+        }
+        __syncthreads();   // pairs with the barrier after the compute waves' epilogue
+      }
+      return;
+    }
+  }
   // ---- prologue: NST-1 stream positions in flight, the first one landed ----
   STAMP(p, 0)
-  item_setup();
-  int issued = 0;
+  if (is_ldr) {
+    item_setup();
+    int issued = 0;
 #pragma unroll
-  for (int j = 0; j < NST - 1; ++j)
-    if (fetch_next(j)) ++issued;
-  if (issued == NST - 1) wait_dma(std::integral_constant<int, NST - 2>{});
-  else wait_dma(std::integral_constant<int, 0>{});
+    for (int j = 0; j < NST - 1; ++j)
+      if (fetch_next(j)) ++issued;
+    if (issued == NST - 1) wait_dma(std::integral_constant<int, NST - 2>{});
+    else wait_dma(std::integral_constant<int, 0>{});
+  }
   __syncthreads();
 
   STAMP(p, 1)
@@ -594,25 +631,31 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(const 
     _Pragma("unroll") for (int a = 0; a < NF; ++a) asm volatile("" ::"v"(WF[a].x), "v"(WF[a].w));       \
     _Pragma("unroll") for (int b = 0; b < MF; ++b) asm volatile("" ::"v"(XF[b].x), "v"(XF[b].w));       \
   }
-      IGEMM_READ(wfA, xfA, cur, fr_c0)
+      if (is_cmp) IGEMM_READ(wfA, xfA, cur, fr_c0)
       for (int kt = kb; kt < ke; ++kt) {
-        const bool more = DBG(p, 1) ? false : fetch_next(fst);
-        IGEMM_READ(wfB, xfB, cur, fr_c1)
-        __builtin_amdgcn_sched_barrier(0);
-        IGEMM_MMA(wfA, xfA)
-        __builtin_amdgcn_sched_barrier(0);
-        // B is in registers, so nobody still reads this stage; the next stream position must have
-        // landed before anyone reads it (later ones may stay in flight)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (more) wait_dma(std::integral_constant<int, NST - 2>{});
-        else wait_dma(std::integral_constant<int, 0>{});
+        bool more = false;
+        if (is_ldr) more = DBG(p, 1) ? false : fetch_next(fst);
+        if (is_cmp) {
+          IGEMM_READ(wfB, xfB, cur, fr_c1)
+          __builtin_amdgcn_sched_barrier(0);
+          IGEMM_MMA(wfA, xfA)
+          __builtin_amdgcn_sched_barrier(0);
+          // B is in registers, so nobody still reads this stage
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        if (is_ldr) {   // the next stream position must have landed before anyone reads it (later ones may stay in flight)
+          if (more) wait_dma(std::integral_constant<int, NST - 2>{});
+          else wait_dma(std::integral_constant<int, 0>{});
+        }
         __syncthreads();
         cur = (cur + 1 == NST) ? 0 : cur + 1;
         fst = (fst + 1 == NST) ? 0 : fst + 1;
-        if (kt + 1 < ke) IGEMM_READ(wfA, xfA, cur, fr_c0)   // (an item's first A read follows its predecessor's epilogue)
-        __builtin_amdgcn_sched_barrier(0);
-        IGEMM_MMA(wfB, xfB)
-        __builtin_amdgcn_sched_barrier(0);
+        if (is_cmp) {
+          if (kt + 1 < ke) IGEMM_READ(wfA, xfA, cur, fr_c0)   // (an item's first A read follows its predecessor's epilogue)
+          __builtin_amdgcn_sched_barrier(0);
+          IGEMM_MMA(wfB, xfB)
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
 #undef IGEMM_READ
 #undef IGEMM_MMA
@@ -652,7 +695,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, 2) void igemm_kernel(const 
     }
     // the DMA of the next item's first tiles is already in flight while this epilogue runs
     if (c_item == first_item) { STAMP(p, 2) }
-    if (!DBG(p, 16)) {
+    if (!DBG(p, 16) && is_cmp) {
       constexpr int E = 16 / (int)sizeof(T);
       const bool rows_ok = p.epi == EPI_STORE && p.splits <= 1 && !DBG(p, 32) && (p.n_valid % E == 0) &&
                            (p.ldo % E == 0) && (!p.resid || p.ldr % E == 0);
@@ -723,7 +766,7 @@ void* g_tsbuf = nullptr;   // s_memtime stamp buffer (LDMSEG_IGEMM_ABLATE builds
 int g_big = 29;      // bit0: 8-wave 256-row tiles with a 3-stage ring (-0.15 ms per forward, on);
                      // bit1: 4-stage ring, one workgroup per CU, for mid-size grids (+0.5 ms, off)
 
-template <typename T, int BM, int BN, int WM, int WN, int NST = 2, bool PIPE = false>
+template <typename T, int BM, int BN, int WM, int WN, int NST = 2, bool PIPE = false, int LDR = 0>
 int run(const IgemmParams& pin, hipStream_t s) {
   IgemmParams p = pin;
   p.dbg = g_dbg;
@@ -734,17 +777,17 @@ int run(const IgemmParams& pin, hipStream_t s) {
   const int nwork = mt * nt * (p.splits > 1 ? p.splits : 1);
   // persistent grid: as many workgroups as fit on the chip at once (2 per CU for the 4-wave tiles,
   // 1 per CU for the 8-wave ones); each walks nwork / grid items
-  int resident = num_cus() * ((WM * WN == 4 && NST == 2) ? 2 : 1);
+  int resident = num_cus() * ((WM * WN == 4 && NST == 2 && LDR == 0) ? 2 : 1);
   const int grid_x = nwork < resident ? nwork : resident;
   const size_t lds = (size_t)NST * (BM + BN) * kRowBytes +
                      (epi_stage_dedicated<BM, BN, WM, WN>() ? epi_stage_bytes<BM, BN, WM, WN>() : 0);
-  auto kern = igemm_kernel<T, BM, BN, WM, WN, NST, PIPE>;
+  auto kern = igemm_kernel<T, BM, BN, WM, WN, NST, PIPE, LDR>;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(grid_x), dim3(WM * WN * 64), lds, s, p);
+  hipLaunchKernelGGL(kern, dim3(grid_x), dim3((WM * WN + LDR) * 64), lds, s, p);
   if (p.splits > 1) {
     const size_t total = (size_t)p.M * (p.n_valid >> 2);
     int blocks = (int)((total + 255) / 256);
@@ -780,6 +823,10 @@ int dispatch(const IgemmParams& p, hipStream_t s) {
   // at most one workgroup per CU anyway: the DMA round trip (~1.1 us) is then hidden only by the
   // workgroup's own ring, so run it four stages deep instead of two
   const bool mid8 = !big && bn >= 128 && p.epi != EPI_GEGLU && mid8_ok(t128, p.splits);
+  // long K slices: 4 compute waves (64x80 each) + 4 loader waves, 4-stage ring - measured 3-15 % faster than the 8-wave
+  // form on the >= 45-tile conv launches of the 16x16 / 32x32 maps and slower on short K (policy bit 1 turns it off)
+  if (mid8 && !(g_big & 2) && (p.taps * (p.C0 + p.C1) / (int)(kRowBytes / sizeof(T))) / (p.splits > 1 ? p.splits : 1) >= 40)
+    return bn == 160 ? run<T, 128, 160, 2, 2, 4, true, 4>(p, s) : run<T, 128, 128, 2, 2, 4, true, 4>(p, s);
   if (mid8) return bn == 160 ? run<T, 128, 160, 4, 2, 3, true>(p, s) : run<T, 128, 128, 4, 2, 3, true>(p, s);
   const long t64 = (long)((p.M + 63) / 64) * (p.N / bn) * (p.splits > 1 ? p.splits : 1);
   const bool lone = (g_big & 4) && small && !big && !deep && t64 <= num_cus();
