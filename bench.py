@@ -29,45 +29,136 @@ import torch  # noqa: E402
 SCHED_KW = dict(prediction_type="epsilon", beta_schedule="scaled_linear", num_train_timesteps=1000,
                 beta_start=0.00085, beta_end=0.012, clip_sample=False, set_alpha_to_one=False)
 FLOP_UNET_L64 = 771.4e9      # per image-step, SURVEY 8(d) / BASELINE.md section 2
+FLOP_UNET = {32: 169.9e9, 64: 771.4e9, 128: 4555.2e9}   # per image-step by latent size (attention grows with L^4)
 FLOP_DEC_L64 = 49.5e9        # seg-VAE decode per image
 PEAK_BF16 = 2.5e15           # dense MFMA bf16, MI355X_MICROARCH.md
 PEAK_F32 = 157.3e12
 
 
-def cpu_baseline(usd, budget_s=25.0):
-    """The oracle (a torch-CPU port of the reference path) on this host's cores: UNet forward,
-    B=1, L=64, fp32 - a bounded sample of the same workload.  torch's intra-op pool is badly
-    oversubscribed with one thread per hardware thread on the 256-thread hosts (46-108 s per forward
-    against ~3 s with 32 threads), so the thread count is picked from a short sweep and reported as
-    `cores`."""
+def host_cpu_info():
+    """Host CPU model, sockets, physical cores and hardware threads from /proc/cpuinfo."""
+    model, cores, threads = "unknown", set(), 0
+    try:
+        phys = core = None
+        with open("/proc/cpuinfo") as fh:
+            for ln in fh:
+                if ln.startswith("model name") and model == "unknown":
+                    model = ln.split(":", 1)[1].strip()
+                elif ln.startswith("processor"):
+                    threads += 1
+                elif ln.startswith("physical id"):
+                    phys = ln.split(":")[1].strip()
+                elif ln.startswith("core id"):
+                    core = ln.split(":")[1].strip()
+                    cores.add((phys, core))
+    except OSError:
+        pass
+    ncores = len(cores) or (os.cpu_count() or 1)
+    return {"model": model, "physical_cores": ncores, "hw_threads": threads or (os.cpu_count() or 1),
+            "sockets": len({c[0] for c in cores}) or 1}
+
+
+def one_thread_per_core(n):
+    """Logical CPU ids of the first n physical cores (one hardware thread each), or None if unknown."""
+    seen, cpus = set(), []
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        for cpu in allowed:
+            base = f"/sys/devices/system/cpu/cpu{cpu}/topology/"
+            with open(base + "physical_package_id") as a, open(base + "core_id") as b:
+                key = (a.read().strip(), b.read().strip())
+            if key not in seen:
+                seen.add(key)
+                cpus.append(cpu)
+            if len(cpus) == n:
+                break
+    except OSError:
+        return None
+    return cpus if len(cpus) == n else None
+
+
+def cpu_baseline(usd, budget_s=30.0):
+    """The oracle (a torch-CPU port of the reference path) on this host's cores: UNet forward at L=64, fp32 - a bounded
+    sample of the same workload.  The thread count is swept from 16 up to the number of PHYSICAL cores, each setting
+    pinned to one hardware thread per core (torch's intra-op pool is pathologically oversubscribed with one thread per
+    hardware thread on the 256-thread hosts: 46-108 s per forward); the best B=1 setting is reported as `value` and
+    re-used for one B=8 forward (the batch the GPU line is quoted on)."""
     from oracle import unet as o_unet
-    x = torch.randn(1, 12, 64, 64, generator=torch.Generator().manual_seed(0))
+    info = host_cpu_info()
+    x = torch.randn(8, 12, 64, 64, generator=torch.Generator().manual_seed(0))
     t = torch.tensor(499)
-    ncpu = os.cpu_count() or 1
-    cands = sorted({min(ncpu, n) for n in (16, 32, 64)})
+    ncores = info["physical_cores"]
+    cands = sorted({min(ncores, n) for n in (16, 32, 64, ncores)})
+    saved_aff = None
+    try:
+        saved_aff = os.sched_getaffinity(0)
+    except (AttributeError, OSError):
+        pass
     t_start = time.perf_counter()
-    best_nt, best = cands[0], float("inf")
+    sweep, best_nt, best = {}, cands[0], float("inf")
     n_fwd = 0
+
+    def pin(nt):
+        cpus = one_thread_per_core(nt) if saved_aff is not None else None
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+        torch.set_num_threads(nt)
+        return bool(cpus)
+
+    pinned = False
     with torch.no_grad():
         for nt in cands:
-            torch.set_num_threads(nt)
+            if saved_aff is not None:
+                os.sched_setaffinity(0, saved_aff)
+            pinned = pin(nt)
             t0 = time.perf_counter()
-            o_unet.unet_forward(usd, x, t)
+            o_unet.unet_forward(usd, x[:1], t)
             dt = time.perf_counter() - t0
             n_fwd += 1
+            sweep[nt] = round(dt, 3)
             if dt < best:
                 best_nt, best = nt, dt
-            if time.perf_counter() - t_start > budget_s:
+            if time.perf_counter() - t_start > 0.5 * budget_s:
                 break
-        torch.set_num_threads(best_nt)
-        while time.perf_counter() - t_start + best < budget_s and n_fwd < 12:
+        if saved_aff is not None:
+            os.sched_setaffinity(0, saved_aff)
+        pinned = pin(best_nt)
+        while time.perf_counter() - t_start + best < 0.55 * budget_s and n_fwd < 10:
             t0 = time.perf_counter()
-            o_unet.unet_forward(usd, x, t)
+            o_unet.unet_forward(usd, x[:1], t)
             best = min(best, time.perf_counter() - t0)
             n_fwd += 1
-    return {"value": 1.0 / best, "unit": "image-steps/s", "cores": best_nt, "kind": "port",
-            "sample": f"oracle UNet forward, B=1, L=64, fp32, {n_fwd} forwards over thread counts {cands}, "
-                      f"best {best:.2f}s at {best_nt} threads ({time.perf_counter() - t_start:.0f}s of CPU work)"}
+        b8 = None
+        if time.perf_counter() - t_start + 6 * best < 1.2 * budget_s:
+            t0 = time.perf_counter()
+            o_unet.unet_forward(usd, x, t)
+            b8 = time.perf_counter() - t0
+    if saved_aff is not None:
+        os.sched_setaffinity(0, saved_aff)
+    out = {"value": 1.0 / best, "unit": "image-steps/s", "cores": best_nt, "kind": "port",
+           "host": info, "threads_used": best_nt, "pinned_one_thread_per_core": pinned,
+           "sweep_s_per_forward_b1": sweep,
+           "sample": f"oracle UNet forward, L=64, fp32: {n_fwd} B=1 forwards over thread counts {cands} (one thread per "
+                     f"physical core, pinned), best {best:.2f}s at {best_nt} threads"
+                     + (f"; one B=8 forward {b8:.2f}s" if b8 else "")
+                     + f" ({time.perf_counter() - t_start:.0f}s of CPU work)"}
+    if b8:
+        out["value_b8"] = 8.0 / b8
+    return out
+
+
+def csrc_hash():
+    """sha256 over the kernel sources: measurements that cannot be taken inside this process (PMC passes) carry the hash
+    they were taken on and are reported as null once the sources moved on."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "latent-diffusion-segmentation_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            with open(os.path.join(d, name), "rb") as fh:
+                h.update(name.encode())
+                h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def kl_encoder_flops(H, W):
@@ -101,6 +192,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-images", action="store_true", help="skip the 50-step images/s run")
     ap.add_argument("--profile-steps", type=int, default=3)
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the fp32 parity-mode, inpainting (configs[3]) and 1024x1024 (configs[4]) side measurements")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -113,7 +206,19 @@ def main():
     # LDMSEG_BENCH_BACKEND=gloo lets the multi-rank control flow be exercised on a box with fewer GPUs than ranks
     # (ranks then share devices); the measured configuration is one rank per GPU over RCCL ("nccl")
     backend = os.environ.get("LDMSEG_BENCH_BACKEND", "nccl")
-    local_rank %= max(1, torch.cuda.device_count())
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    if backend == "nccl":
+        # the measured configuration: one rank per GPU over RCCL.  Over-subscription is an error, never a silent remap
+        # (RCCL hangs or fails on duplicate devices)
+        if world > ndev or local_rank >= ndev:
+            raise SystemExit(f"--gpus {world} needs {world} visible devices, found {ndev} "
+                             f"(LDMSEG_BENCH_BACKEND=gloo exercises the control flow with ranks sharing devices)")
+    else:
+        local_rank %= ndev
+    distinct_devices = min(world, ndev)
+    ranks_share_device = world > ndev
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -244,14 +349,17 @@ def main():
         # HBM traffic per launch of the same kernels from the PMC passes kept under profiles/ (FETCH_SIZE x2 per the
         # gfx950 correction + WRITE_SIZE); rocprofv3 cannot run inside this process, so the figure is the committed
         # measurement of this very command, or null when the file is absent
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tf) and args.dtype == "bf16" and (B, L) == (8, 64):
-            with open(tf) as fh:
-                traffic = json.load(fh).get("hbm_bytes_per_launch")
+        traffic, traffic_src = None, None
+        cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))
+        if cands and args.dtype == "bf16" and (B, L) == (8, 64):
+            with open(os.path.join(ROOT, "profiles", cands[-1])) as fh:
+                tj = json.load(fh)
+            if tj.get("csrc_sha") == csrc_hash():       # stale (kernels changed since the PMC passes) -> null
+                traffic, traffic_src = tj.get("hbm_bytes_per_launch"), "profiles/" + cands[-1]
         roofline = {"bound": "mfma", "kernel": "igemm_kernel (conv3x3/conv1x1/Linear)", "achieved": ach / 1e12,
                     "peak": peak / 1e12, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
-                    "traffic_unit": "HBM bytes per launch (PMC, profiles/r01_pmc_traffic.json)",
+                    "traffic_unit": "HBM bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, separate passes)",
+                    "traffic_source": traffic_src, "csrc_sha": csrc_hash(),
                     "alg_bytes_per_launch": ig["bytes"] / max(1, ig["launches"]),
                     "launches": ig["launches"], "avg_launch_us": 1e3 * ig["ms"] / max(1, ig["launches"]),
                     "alg_flops_per_launch": ig["flops"] / max(1, ig["launches"]),
@@ -261,6 +369,49 @@ def main():
     if world > 1:
         dist.barrier()
 
+    # ---- side measurements (rank 0, single GPU): the other BASELINE configs and the fp32 parity mode ----
+    extras = {}
+    if rank == 0 and world == 1 and not args.no_extras:
+        def timed(tr_, Bx, Lx, k, fn=None):
+            rgbx = (0.18215 * torch.randn(Bx, 4, Lx, Lx, generator=torch.Generator().manual_seed(99))).to(dev)
+            def go(n):
+                sx = DDIMNoiseScheduler(**SCHED_KW)
+                sx.set_timesteps_inference(n)
+                if fn is not None:
+                    return fn(tr_, rgbx, sx)
+                return tr_.sample([""] * Bx, num_inference_steps=n, seed=42, rgb_latents=rgbx, scheduler=sx)
+            go(2)
+            torch.cuda.synchronize(dev)
+            t0_ = time.perf_counter()
+            o_ = go(k)
+            torch.cuda.synchronize(dev)
+            dt_ = time.perf_counter() - t0_
+            assert torch.isfinite(o_).all()
+            return {"batch": Bx, "latent": Lx, "steps": k, "ms_per_step": 1e3 * dt_ / k, "image_steps_per_s": Bx * k / dt_,
+                    "mfma_frac_of_dtype_peak": None}
+        # BASELINE configs[4]: 1024x1024 -> 128x128x4 latents, batch 4 (N = 16384 tokens in the first attention level)
+        r128 = timed(tr, 4, 128, 5)
+        r128["whole_step_mfma_frac"] = r128["image_steps_per_s"] * FLOP_UNET[128] / PEAK_BF16
+        r128["attention_path"] = os.environ.get("LDMSEG_ATTN_PATH", "default")
+        extras["config4_1024px_b4_l128_" + args.dtype] = r128
+        # BASELINE configs[3]: mask inpainting, batch 16, 50 % of the latents known
+        def inpaint(tr_, rgbx, sx):
+            gi = torch.Generator().manual_seed(7)
+            z0 = (0.2 * torch.randn(rgbx.shape, generator=gi)).to(dev)
+            known = (torch.rand(rgbx.shape[0], 1, rgbx.shape[2], rgbx.shape[3], generator=gi) < 0.5).to(dev)
+            return tr_.sample_inpaint([""] * rgbx.shape[0], known, z0, seed=42, rgb_latents=rgbx, scheduler=sx)
+        extras["config3_inpaint_b16_l64_" + args.dtype] = timed(tr, 16, 64, 10, inpaint)
+        # fp32 parity mode (the mode the 1e-3 parity claims are made in), same workload as the headline line
+        if args.dtype == "bf16":
+            unet32 = UNet(usd, in_channels=12, device=dev, compute_dtype="fp32")
+            tr32 = TrainerDiffusion(None, unet32, DDIMNoiseScheduler(**SCHED_KW))
+            r32 = timed(tr32, B, L, 5)
+            r32["whole_step_frac_of_f32_mfma_peak"] = r32["image_steps_per_s"] * FLOP_UNET.get(L, FLOP_UNET_L64) / PEAK_F32
+            extras["fp32_parity_mode"] = r32
+            del unet32, tr32
+        for v_ in extras.values():
+            v_.pop("mfma_frac_of_dtype_peak", None)
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         del unet, vae
@@ -269,22 +420,32 @@ def main():
     if rank == 0:
         n_img_steps = B * world * args.steps
         value = n_img_steps / elapsed
-        flop_step = FLOP_UNET_L64 * (L / 64.0) ** 2 if L != 64 else FLOP_UNET_L64
+        flop_step = FLOP_UNET.get(L, FLOP_UNET_L64 * (L / 64.0) ** 2)
+        px = 8 * L
+        workload = (f"{px}x{px} COCO-shaped latents ({L}x{L}x4), batch {B} per GPU, DDIM, self-conditioned 12-ch UNet "
+                    f"without cross-attention"
+                    + (" (BASELINE configs[1])" if (B, L, args.dtype) == (8, 64, "bf16") and world == 1 else "")
+                    + (" (BASELINE configs[2] when 8 GPUs)" if (B, L, args.dtype) == (8, 64, "bf16") and world > 1 else "")
+                    + (" (BASELINE configs[4] shape)" if (B, L) == (4, 128) else ""))
         out = {
-            "metric": "denoising-steps/sec", "value": value, "unit": "image-steps/s", "n_gpus": world,
+            "metric": "denoising-steps/sec", "value": value, "unit": "image-steps/s", "n_gpus": distinct_devices,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
             "data": "synthetic (random-init SD-1.x UNet + seg-VAE weights, synthetic rgb latents)",
-            "config": {"workload": "512x512 COCO-shaped latents (64x64x4), batch 8 per GPU, DDIM, self-conditioned "
-                                   "12-ch UNet without cross-attention (BASELINE configs[1])",
-                       "batch_per_gpu": B, "global_batch": B * world, "latent": L, "parallelism": f"dp{world}"},
+            "config": {"workload": workload, "batch_per_gpu": B, "global_batch": B * world, "latent": L,
+                       "parallelism": f"dp{distinct_devices}", "ranks": world, "backend": backend if world > 1 else "none",
+                       "visible_devices": ndev, "ranks_share_device": ranks_share_device},
             "images_per_s_50step_ddim_incl_decode": images_per_s,
             "whole_step_mfma_frac": (B * flop_step * args.steps / elapsed) / (PEAK_BF16 if args.dtype == "bf16" else PEAK_F32),
             "roofline": roofline,
             "postprocess_8f1": postprocess,
             "image_encoder_8f2": image_encoder,
+            "other_configs": extras or None,
             "cpu_baseline": cpu,
         }
+        if ranks_share_device:
+            out["note"] = ("control-flow run: several ranks shared one GPU (LDMSEG_BENCH_BACKEND=gloo); this is NOT a "
+                           "multi-GPU measurement")
         if cpu:
             out["gpu_over_cpu"] = value / cpu["value"]
         print(json.dumps(out))

@@ -11,14 +11,20 @@
  *     handle's GPU; boundary tensors are fp32 NCHW contiguous (the reference's
  *     layout); timesteps are int64.
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls
- *     only enqueue work; they never synchronise the stream or the device.
+ *     only enqueue work.  The one exception is workspace growth: the first call of a
+ *     handle at a (B, L) larger than any before (re)allocates its workspace, which
+ *     synchronises the device.  ldmseg_unet_reserve() does that up front, after which
+ *     forward / sample_loop calls at that size never allocate or synchronise (and are
+ *     safe under stream capture).  *_create calls allocate and synchronise.
  *   - return 0 on success, negative LDMSEG_E_* on failure; ldmseg_last_error()
  *     returns a thread-local message.  No C++ exception crosses the boundary.
  *   - the library owns handles, repacked weights and workspaces; the caller owns
  *     every tensor it passes and keeps it alive until the stream work is done.
  *     Weights are copied/repacked at create time.
- *   - a handle is bound to one device and is not thread-safe (one process per GPU,
- *     like tools/main_ldm.py:69 mp.spawn).
+ *   - a handle is bound to cfg.device and is not thread-safe (one process per GPU,
+ *     like tools/main_ldm.py:69 mp.spawn).  Every call on a handle makes that device
+ *     current for its duration and restores the caller's; the handle-free calls
+ *     (ddim_step, add_noise, ...) run on the calling thread's current device.
  */
 #ifndef LDMSEG_HIP_H_
 #define LDMSEG_HIP_H_
@@ -81,6 +87,10 @@ int ldmseg_unet_forward(ldmseg_unet* h, const float* x, const int64_t* t_dev, in
 int ldmseg_unet_forward_parts(ldmseg_unet* h, const float* latents, const float* rgb_latents, const float* cond,
                               const int64_t* t_dev, int t_count, int64_t t_host, int B, int L, float* out,
                               void* stream);
+/* Allocate everything forward / sample_loop need at (B, L) now (workspace + the sampler's eps and
+ * self-condition buffers); may synchronise the device.  Optional: without it the first call at a new,
+ * larger shape does the same lazily. */
+int ldmseg_unet_reserve(ldmseg_unet* h, int B, int L);
 /* bytes of device workspace a forward at (B, L) needs (allocated lazily, grown never shrunk) */
 size_t ldmseg_unet_workspace_bytes(const ldmseg_unet* h, int B, int L);
 /* number of parameters held (815,556,484 for the 12-channel default) */
@@ -176,13 +186,16 @@ int ldmseg_ddim_step(const float* model_output, const float* sample, float sqrt_
                      float clip_sample_range, int use_clipped_model_output, float* prev_sample,
                      float* pred_original_sample, size_t n, void* stream);
 /* add_noise (:155-187) / remove_noise (:190-216) with per-sample int64 timesteps [B] and the
- * fp32 alphas_cumprod table on device. */
+ * fp32 alphas_cumprod table [n_train_timesteps] on device.  The reference raises IndexError for a
+ * timestep outside [0, n_train_timesteps); device-resident timesteps cannot be inspected without a
+ * sync, so the kernel clamps the index into the table (never an out-of-bounds read) and the Python
+ * wrapper raises IndexError whenever it is handed host-resident timesteps. */
 int ldmseg_add_noise(const float* original, const float* noise, const int64_t* timesteps_dev,
-                     const float* alphas_cumprod_dev, float scale, float* out, int B, size_t per_sample,
-                     void* stream);
+                     const float* alphas_cumprod_dev, int n_train_timesteps, float scale, float* out, int B,
+                     size_t per_sample, void* stream);
 int ldmseg_remove_noise(const float* noisy, const float* noise, const int64_t* timesteps_dev,
-                        const float* alphas_cumprod_dev, float scale, float* out, int B, size_t per_sample,
-                        void* stream);
+                        const float* alphas_cumprod_dev, int n_train_timesteps, float scale, float* out, int B,
+                        size_t per_sample, void* stream);
 
 /* ---- sampler: TrainerDiffusion.sample (trainers_ldm_cond.py:1045-1170) -------------------- */
 typedef struct {
@@ -227,6 +240,8 @@ int ldmseg_profile_dump(const char* path);
  * -DLDMSEG_IGEMM_ABLATE builds only, phase-ablation flags in value[0..7]); key 2 = attention query-tile choice;
  * keys 3/4 = low/high half of a device buffer for per-workgroup s_memtime stamps (ablate builds). */
 int ldmseg_debug_set(int key, int value);
+/* current value of a knob (key 1); key -1 = the shipped default of key 1.  Tests restore through this, never a literal. */
+int ldmseg_debug_get(int key);
 
 #ifdef __cplusplus
 }

@@ -35,6 +35,23 @@ int ldmseg_op_convt2(const float* x, const float* w, const float* bias, int B, i
 /* F.interpolate(scale_factor=2, mode='bilinear', align_corners=False)  (vae.py:270) */
 int ldmseg_op_bilinear2x(const float* x, int B, int C, int H, int W, int dtype, float* out, void* stream);
 
+/* One conv / GEMM layer launched exactly as the engine launches it inside a forward (NHWC operands, the engine's
+ * split-K plan when splits == 0, row-major store epilogue with bias / per-image bias row / residual / SiLU, or GEGLU):
+ * F.conv2d(cat([x,x2],1) [nearest x2 if up], w, bias, stride, k/2) + rowbias[b,:,None,None] + resid, then SiLU;
+ * geglu=1: w [Co,Ci] is ff.net.0.proj, out = a * gelu(gate) with [a | gate] = chunk(2, dim=1), Cout = Co/2.
+ * NCHW f32 boundary like the other ops. */
+int ldmseg_op_igemm(const float* x, const float* x2, const float* w, const float* bias, const float* resid,
+                    const float* rowbias, int B, int Ci, int Ci2, int H, int W, int Co, int k, int stride, int up, int geglu,
+                    int silu, int splits, int dtype, float* out, void* stream);
+/* "igemm<dtype,BM,BN,WM,WN,NST,PIPE,LDR> splits=S grid=G": template instantiation and plan of the most recent igemm
+ * launch of this process - lets a parity test assert WHICH kernel it just compared with the oracle. */
+int ldmseg_igemm_last_kernel(char* buf, int n);
+/* enable=1 clears and starts a log of the DISTINCT igemm instantiations launched ("igemm<...>" + "/splitk" for K-sliced
+ * launches), enable=0 stops it; _read copies them newline-separated.  The parity suite uses it to prove that every
+ * instantiation a full-size forward runs is also compared with the oracle by a per-layer test. */
+int ldmseg_igemm_log(int enable);
+int ldmseg_igemm_log_read(char* buf, int n);
+
 #ifdef __cplusplus
 }
 #endif

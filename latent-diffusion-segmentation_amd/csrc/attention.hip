@@ -332,10 +332,12 @@ int run(const void* qkv, void* out, int B, int N, int C, int heads, hipStream_t 
   const size_t stage = (size_t)(Cfg::KS_BYTES + Cfg::VT_BYTES);
   const size_t lds = (2 * stage <= 144 * 1024 ? 2 : 1) * stage;
   auto kern = attention_kernel<T, D, QF>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[64] = {};     // per device: a process may hold handles on several GPUs
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!attr_set[dev]) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
+    attr_set[dev] = true;
   }
   const int nqb = (N + 64 * QF - 1) / (64 * QF);
   const float scale_log2e = (1.0f / sqrtf((float)D)) * 1.4426950408889634f;

@@ -42,6 +42,19 @@ int fail(int code, const std::string& msg) {
     }                                                                                         \
   } while (0)
 
+// Makes `device` current for the duration of a call on a handle (a process may hold handles on several GPUs; the
+// kernels, workspaces and per-device launcher state of a handle all belong to cfg.device) and restores the caller's.
+struct DeviceGuard {
+  int prev = -1;
+  bool changed = false;
+  explicit DeviceGuard(int device) {
+    if (hipGetDevice(&prev) == hipSuccess && prev != device) changed = hipSetDevice(device) == hipSuccess;
+  }
+  ~DeviceGuard() {
+    if (changed) (void)hipSetDevice(prev);
+  }
+};
+
 inline size_t rup(size_t v, size_t a) { return (v + a - 1) / a * a; }
 inline size_t esize(int dt) { return dt == DT_BF16 ? 2 : 4; }
 inline int bke(int dt) { return dt == DT_BF16 ? 64 : 32; }  // channels per 128-B K tile
@@ -1075,7 +1088,7 @@ int ldmseg_unet_create(const ldmseg_unet_cfg* cfg, int n_weights, const char* co
   if (cfg->cross_attention) return fail(LDMSEG_E_ARG, "cross-attention (encoder_hidden_states) is not supported: the reference default removes it (base.yaml:71)");
   if (cfg->compute_dtype != LDMSEG_F32 && cfg->compute_dtype != LDMSEG_BF16) return fail(LDMSEG_E_ARG, "bad compute_dtype");
   if (cfg->in_channels != 4 && cfg->in_channels != 8 && cfg->in_channels != 12) return fail(LDMSEG_E_ARG, "in_channels must be 4, 8 or 12");
-  HIP_TRY(hipSetDevice(cfg->device));
+  DeviceGuard dg(cfg->device);
   TRY(check_arch(cfg->device));
   WeightMap wm;
   TRY(make_weight_map(n_weights, names, dev_ptrs, numels, &wm));
@@ -1095,6 +1108,7 @@ int64_t ldmseg_unet_num_params(const ldmseg_unet* h) { return h ? h->nparams : 0
 size_t ldmseg_unet_workspace_bytes(const ldmseg_unet* h, int B, int L) {
   if (!h) return 0;
   ldmseg_unet* u = const_cast<ldmseg_unet*>(h);
+  DeviceGuard dg(u->cfg.device);
   const int ci = u->cfg.in_channels;
   if (unet_forward_impl(u, nullptr, ci, nullptr, 0, nullptr, 0, nullptr, 1, 0, B, L, nullptr, nullptr, true, 0) != 0) return 0;
   return rup(u->ws.persist_peak, 4096) + rup(u->ws.scratch_peak, 4096);
@@ -1104,6 +1118,7 @@ int ldmseg_unet_forward(ldmseg_unet* h, const float* x, const int64_t* t_dev, in
                         float* out, void* stream) {
   g_err.clear();
   if (!h || !x || !out) return fail(LDMSEG_E_ARG, "null argument");
+  DeviceGuard dg(h->cfg.device);
   return unet_forward_checked(h, x, h->cfg.in_channels, nullptr, 0, nullptr, 0, t_dev, t_count, t_host, B, L, out,
                               (hipStream_t)stream);
 }
@@ -1112,6 +1127,7 @@ int ldmseg_unet_forward_parts(ldmseg_unet* h, const float* latents, const float*
                               const int64_t* t_dev, int t_count, int64_t t_host, int B, int L, float* out, void* stream) {
   g_err.clear();
   if (!h || !latents || !rgb_latents || !out) return fail(LDMSEG_E_ARG, "null argument");
+  DeviceGuard dg(h->cfg.device);
   return unet_forward_checked(h, latents, 4, rgb_latents, 4, cond, cond ? 4 : 0, t_dev, t_count, t_host, B, L, out,
                               (hipStream_t)stream);
 }
@@ -1122,7 +1138,7 @@ int ldmseg_vae_create(const ldmseg_vae_cfg* cfg, int n_weights, const char* cons
   if (!cfg || !out) return fail(LDMSEG_E_ARG, "null argument");
   if (cfg->compute_dtype != LDMSEG_F32 && cfg->compute_dtype != LDMSEG_BF16) return fail(LDMSEG_E_ARG, "bad compute_dtype");
   if (cfg->num_latents != 2 || cfg->norm_num_groups != 32) return fail(LDMSEG_E_ARG, "only the gaussian parametrization with 32 groups is supported");
-  HIP_TRY(hipSetDevice(cfg->device));
+  DeviceGuard dg(cfg->device);
   TRY(check_arch(cfg->device));
   WeightMap wm;
   TRY(make_weight_map(n_weights, names, dev_ptrs, numels, &wm));
@@ -1141,6 +1157,7 @@ int ldmseg_vae_decode(ldmseg_vae* h, const float* z, float z_scale, int B, int L
                       void* stream) {
   g_err.clear();
   if (!h || !z || !logits) return fail(LDMSEG_E_ARG, "null argument");
+  DeviceGuard dg(h->cfg.device);
   if (B < 1 || L < 1) return fail(LDMSEG_E_SHAPE, "bad B/L");
   TRY(vae_decode_impl(h, z, z_scale, B, L, interpolate, logits, (hipStream_t)stream, true, 0));
   const size_t persist = rup(h->ws.persist_peak, 4096), scratch = rup(h->ws.scratch_peak, 4096);
@@ -1152,6 +1169,7 @@ int ldmseg_vae_decode_argmax(ldmseg_vae* h, const float* z, float z_scale, int B
                              int64_t* ids, float* max_prob, void* stream) {
   g_err.clear();
   if (!h || !z || !ids) return fail(LDMSEG_E_ARG, "null argument");
+  DeviceGuard dg(h->cfg.device);
   if (B < 1 || L < 1) return fail(LDMSEG_E_SHAPE, "bad B/L");
   if (h->cfg.num_upscalers != 2) return fail(LDMSEG_E_ARG, "the fused tail assumes interpolation_factor 2 (num_upscalers 2)");
   ArgmaxOut am{ids, max_prob, mask_th, ignore_label};
@@ -1165,6 +1183,7 @@ int ldmseg_vae_encode(ldmseg_vae* h, const float* x, float in_mul, float in_add,
                       void* stream) {
   g_err.clear();
   if (!h || !x || !moments) return fail(LDMSEG_E_ARG, "null argument");
+  DeviceGuard dg(h->cfg.device);
   if (B < 1 || H < 8 || H % 8) return fail(LDMSEG_E_SHAPE, "H must be a multiple of 8");
   TRY(vae_encode_impl(h, x, in_mul, in_add, B, H, moments, (hipStream_t)stream, true, 0));
   const size_t persist = rup(h->ws.persist_peak, 4096), scratch = rup(h->ws.scratch_peak, 4096);
@@ -1177,7 +1196,7 @@ int ldmseg_vae_image_create(const ldmseg_vae_image_cfg* cfg, int n_weights, cons
   g_err.clear();
   if (!cfg || !out) return fail(LDMSEG_E_ARG, "null argument");
   if (cfg->compute_dtype != LDMSEG_F32 && cfg->compute_dtype != LDMSEG_BF16) return fail(LDMSEG_E_ARG, "bad compute_dtype");
-  HIP_TRY(hipSetDevice(cfg->device));
+  DeviceGuard dg(cfg->device);
   TRY(check_arch(cfg->device));
   WeightMap wm;
   TRY(make_weight_map(n_weights, names, dev_ptrs, numels, &wm));
@@ -1196,6 +1215,7 @@ int ldmseg_vae_image_encode(ldmseg_vae_image* h, const float* x, float in_mul, f
                             float* moments, void* stream) {
   g_err.clear();
   if (!h || !x || !moments) return fail(LDMSEG_E_ARG, "null argument");
+  DeviceGuard dg(h->cfg.device);
   if (B < 1 || H < 8 || W < 8 || H % 8 || W % 8) return fail(LDMSEG_E_SHAPE, "H and W must be multiples of 8");
   TRY(klenc_encode_impl(h, x, in_mul, in_add, B, H, W, moments, (hipStream_t)stream, true, 0));
   const size_t persist = rup(h->ws.persist_peak, 4096), scratch = rup(h->ws.scratch_peak, 4096);
@@ -1225,16 +1245,60 @@ int ldmseg_ddim_step(const float* model_output, const float* sample, float sqrt_
   return 0;
 }
 
+static int noise_args_ok(const void* a, const void* noise, const void* t, const void* ac, const void* out, int B,
+                         size_t per, int n_train) {
+  if (!a || !noise || !t || !ac || !out) return fail(LDMSEG_E_ARG, "null argument");
+  if (B < 1 || per < 1 || n_train < 1) return fail(LDMSEG_E_ARG, "B, per_sample and n_train_timesteps must be positive");
+  return 0;
+}
 int ldmseg_add_noise(const float* original, const float* noise, const int64_t* timesteps_dev,
-                     const float* alphas_cumprod_dev, float scale, float* out, int B, size_t per_sample, void* stream) {
+                     const float* alphas_cumprod_dev, int n_train_timesteps, float scale, float* out, int B,
+                     size_t per_sample, void* stream) {
   g_err.clear();
-  TRY(launch_add_noise(original, noise, timesteps_dev, alphas_cumprod_dev, scale, out, B, per_sample, 0, (hipStream_t)stream));
+  TRY(noise_args_ok(original, noise, timesteps_dev, alphas_cumprod_dev, out, B, per_sample, n_train_timesteps));
+  TRY(launch_add_noise(original, noise, timesteps_dev, alphas_cumprod_dev, n_train_timesteps, scale, out, B, per_sample, 0,
+                       (hipStream_t)stream));
   return 0;
 }
 int ldmseg_remove_noise(const float* noisy, const float* noise, const int64_t* timesteps_dev,
-                        const float* alphas_cumprod_dev, float scale, float* out, int B, size_t per_sample, void* stream) {
+                        const float* alphas_cumprod_dev, int n_train_timesteps, float scale, float* out, int B,
+                        size_t per_sample, void* stream) {
   g_err.clear();
-  TRY(launch_add_noise(noisy, noise, timesteps_dev, alphas_cumprod_dev, scale, out, B, per_sample, 1, (hipStream_t)stream));
+  TRY(noise_args_ok(noisy, noise, timesteps_dev, alphas_cumprod_dev, out, B, per_sample, n_train_timesteps));
+  TRY(launch_add_noise(noisy, noise, timesteps_dev, alphas_cumprod_dev, n_train_timesteps, scale, out, B, per_sample, 1,
+                       (hipStream_t)stream));
+  return 0;
+}
+
+// (re)allocate the sampler's eps / self-condition buffers; growth synchronises the device
+static int loop_reserve(ldmseg_unet* h, size_t n) {
+  if (h->loop_elems >= n) return 0;
+  HIP_TRY(hipDeviceSynchronize());
+  if (h->cond) (void)hipFree(h->cond);
+  if (h->eps) (void)hipFree(h->eps);
+  h->cond = h->eps = nullptr;
+  h->loop_elems = 0;
+  HIP_TRY(hipMalloc((void**)&h->cond, n * sizeof(float)));
+  HIP_TRY(hipMalloc((void**)&h->eps, n * sizeof(float)));
+  h->loop_elems = n;
+  return 0;
+}
+
+int ldmseg_unet_reserve(ldmseg_unet* h, int B, int L) {
+  g_err.clear();
+  if (!h) return fail(LDMSEG_E_ARG, "null argument");
+  if (B < 1 || L < 8 || L % 8 != 0) return fail(LDMSEG_E_SHAPE, "L must be a positive multiple of 8, B >= 1");
+  DeviceGuard dg(h->cfg.device);
+  const int ci = h->cfg.in_channels;
+  if (h->plan_B != B || h->plan_L != L) {
+    TRY(unet_forward_impl(h, nullptr, ci, nullptr, 0, nullptr, 0, nullptr, 1, 0, B, L, nullptr, nullptr, true, 0));
+    h->plan_persist = rup(h->ws.persist_peak, 4096);
+    h->plan_scratch = rup(h->ws.scratch_peak, 4096);
+    h->plan_B = B;
+    h->plan_L = L;
+  }
+  TRY(ensure_ws(&h->ws_mem, &h->ws_cap, &h->ws, h->plan_persist + h->plan_scratch));
+  TRY(loop_reserve(h, (size_t)B * 4 * L * L));
   return 0;
 }
 
@@ -1242,19 +1306,17 @@ int ldmseg_sample_loop(ldmseg_unet* h, const ldmseg_sample_cfg* cfg, float* late
                        float* all_latents, void* stream) {
   g_err.clear();
   if (!h || !cfg || !latents || !rgb_latents || !cfg->timesteps || !cfg->coef) return fail(LDMSEG_E_ARG, "null argument");
+  if (cfg->n_steps < 1) return fail(LDMSEG_E_ARG, "n_steps must be >= 1");
+  if (B < 1 || L < 8 || L % 8 != 0) return fail(LDMSEG_E_SHAPE, "L must be a positive multiple of 8, B >= 1");
+  if (cfg->prediction_type < 0 || cfg->prediction_type > 2) return fail(LDMSEG_E_ARG, "unknown prediction_type");
+  for (int i = 0; i < cfg->n_steps; ++i)
+    if (cfg->timesteps[i] < 0) return fail(LDMSEG_E_ARG, "negative timestep");
+  DeviceGuard dg(h->cfg.device);
   hipStream_t s = (hipStream_t)stream;
   const size_t n = (size_t)B * 4 * L * L;
   const bool selfc = cfg->self_condition != 0;
   if ((h->cfg.in_channels == 12) != selfc) return fail(LDMSEG_E_ARG, "self_condition needs the 12-channel conv_in (and vice versa)");
-  if (h->loop_elems < n) {
-    HIP_TRY(hipDeviceSynchronize());
-    if (h->cond) (void)hipFree(h->cond);
-    if (h->eps) (void)hipFree(h->eps);
-    h->cond = h->eps = nullptr;
-    HIP_TRY(hipMalloc((void**)&h->cond, n * sizeof(float)));
-    HIP_TRY(hipMalloc((void**)&h->eps, n * sizeof(float)));
-    h->loop_elems = n;
-  }
+  TRY(loop_reserve(h, n));      // no-op after ldmseg_unet_reserve or a previous call at this size
   const bool inpaint = cfg->known_dev != nullptr;
   if (inpaint && (!cfg->z0_dev || !cfg->noise_dev || !cfg->paste_coef)) return fail(LDMSEG_E_ARG, "inpainting needs z0, noise and paste_coef");
   if (selfc) HIP_TRY(hipMemsetAsync(h->cond, 0, n * sizeof(float), s));   // condition = zeros_like(rgb_latents)
@@ -1346,6 +1408,28 @@ int ldmseg_debug_set(int key, int value) {
   if (key == 3) { ts_ptr = (ts_ptr & 0xffffffff00000000ull) | (unsigned)value; igemm_set_tsbuf((void*)(uintptr_t)ts_ptr); return 0; }
   if (key == 4) { ts_ptr = (ts_ptr & 0xffffffffull) | ((unsigned long long)(unsigned)value << 32); igemm_set_tsbuf((void*)(uintptr_t)ts_ptr); return 0; }
   return fail(LDMSEG_E_ARG, "unknown debug key");
+}
+
+int ldmseg_debug_get(int key) {
+  if (key == 1) return igemm_get_dbg();
+  if (key == -1) return igemm_default_dbg();     // the shipped value of key 1
+  return 0;
+}
+
+// "igemm<bf16,BM,BN,WM,WN,NST,PIPE,LDR>[/splitk] splits=S grid=G" of the most recent igemm launch
+int ldmseg_igemm_last_kernel(char* buf, int n) {
+  if (!buf || n < 1) return LDMSEG_E_ARG;
+  const IgemmDispatch d = igemm_last_dispatch();
+  std::snprintf(buf, (size_t)n, "%s splits=%d grid=%d", igemm_dispatch_name(d).c_str(), d.splits, d.grid);
+  return 0;
+}
+int ldmseg_igemm_log(int enable) { igemm_log_enable(enable); return 0; }
+int ldmseg_igemm_log_read(char* buf, int n) {
+  if (!buf || n < 1) return LDMSEG_E_ARG;
+  const std::string s = igemm_log_read();
+  if ((int)s.size() + 1 > n) return LDMSEG_E_ARG;
+  std::memcpy(buf, s.c_str(), s.size() + 1);
+  return 0;
 }
 
 // one CSV line per recorded launch: family,label,ms,flops

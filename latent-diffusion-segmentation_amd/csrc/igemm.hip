@@ -18,11 +18,15 @@
 //    8-/16-byte stores along the NHWC channel axis and in-lane GEGLU.
 //  * LDS tiles are [rows][128 B] with the 16-B chunk index XOR (row & 7):
 //    conflict-free for ds_read_b128 over the 16-lane groups of gfx950.
-//  * double-buffered LDS filled by LDS-DMA (global_load_lds_dwordx4, no VGPR round trip and no
-//    ds_write pass); the DMA of tile t+1 is issued before the MFMA block of tile t; one barrier
-//    per K tile; 2 workgroups per CU.  Out-of-image taps read a 16-B page of zeros.
+//  * a ring of NST LDS stages (2..4 full K tiles) filled by LDS-DMA (global_load_lds_dwordx4: no VGPR
+//    round trip, no ds_write pass); the DMA stream runs NST-1 tiles ahead of the MFMA stream, also
+//    across work-item boundaries (persistent grid); counted vmcnt + one barrier per K tile.
+//    Out-of-image taps read a 16-B page of zeros.
 //  * workgroup id -> (m tile, n tile) is remapped so that each XCD (own L2)
 //    owns a contiguous range of tiles.
+#include <cstdio>
+#include <set>
+#include <string>
 #include <type_traits>
 
 #include "common.h"
@@ -741,29 +745,46 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const IgemmParams p)
   }
 }
 
+// Per-device state (a process may hold handles on several devices; kernels of a handle always run
+// on that handle's device, which the C ABI makes current before launching).
+constexpr int kMaxDev = 64;
+int cur_dev() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) dev = 0;
+  return dev;
+}
+
 int num_cus() {
-  static int n = 0;
-  if (!n) {
-    int dev = 0;
+  static int n[kMaxDev] = {};
+  const int dev = cur_dev();
+  if (!n[dev]) {
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-    if (n <= 0) n = 256;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) n[dev] = prop.multiProcessorCount;
+    if (n[dev] <= 0) n[dev] = 256;
   }
-  return n;
+  return n[dev];
 }
 
 const void* zero_page() {
-  static void* z = nullptr;
-  if (!z) {
-    if (hipMalloc(&z, 64 << 10) != hipSuccess) return nullptr;     // also serves as an all-zero bias vector
-    (void)hipMemset(z, 0, 64 << 10);
+  static void* z[kMaxDev] = {};
+  const int dev = cur_dev();
+  if (!z[dev]) {
+    if (hipMalloc(&z[dev], 64 << 10) != hipSuccess) return nullptr;     // also serves as an all-zero bias vector
+    (void)hipMemset(z[dev], 0, 64 << 10);
   }
-  return z;
+  return z[dev];
 }
 
+constexpr int kDefaultPolicy = 29;
+}  // namespace
+std::string igemm_dispatch_name(const IgemmDispatch& d);
+namespace {
+bool g_log_on = false;
+std::set<std::string> g_log;   // distinct instantiations launched while logging is on
+IgemmDispatch g_last{};   // what the last launch_igemm on this thread's process ran (parity tests assert on it)
 int g_dbg = 0;       // ablation flags (profiling experiments only)
 void* g_tsbuf = nullptr;   // s_memtime stamp buffer (LDMSEG_IGEMM_ABLATE builds)
-int g_big = 29;      // bit0: 8-wave 256-row tiles with a 3-stage ring (-0.15 ms per forward, on);
+int g_big = kDefaultPolicy;      // bit0: 8-wave 256-row tiles with a 3-stage ring (-0.15 ms per forward, on);
                      // bit1: 4-stage ring, one workgroup per CU, for mid-size grids (+0.5 ms, off)
 
 template <typename T, int BM, int BN, int WM, int WN, int NST = 2, bool PIPE = false, int LDR = 0>
@@ -782,11 +803,15 @@ int run(const IgemmParams& pin, hipStream_t s) {
   const size_t lds = (size_t)NST * (BM + BN) * kRowBytes +
                      (epi_stage_dedicated<BM, BN, WM, WN>() ? epi_stage_bytes<BM, BN, WM, WN>() : 0);
   auto kern = igemm_kernel<T, BM, BN, WM, WN, NST, PIPE, LDR>;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[kMaxDev] = {};
+  const int dev = cur_dev();
+  if (!attr_set[dev]) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
+    attr_set[dev] = true;
   }
+  g_last = IgemmDispatch{(int)sizeof(T) == 2 ? DT_BF16 : DT_F32, BM, BN, WM, WN, NST, PIPE ? 1 : 0, LDR,
+                         p.splits > 1 ? p.splits : 1, grid_x};
+  if (g_log_on) g_log.insert(igemm_dispatch_name(g_last));
   hipLaunchKernelGGL(kern, dim3(grid_x), dim3((WM * WN + LDR) * 64), lds, s, p);
   if (p.splits > 1) {
     const size_t total = (size_t)p.M * (p.n_valid >> 2);
@@ -848,6 +873,22 @@ int dispatch(const IgemmParams& p, hipStream_t s) {
 
 void igemm_set_tsbuf(void* b) { g_tsbuf = b; }
 void igemm_set_dbg(int f) { g_dbg = f & 0xff; g_big = (f >> 8) & 31; }   // bits 8-12 select the tile policy
+int igemm_get_dbg() { return (g_big << 8) | g_dbg; }
+int igemm_default_dbg() { return kDefaultPolicy << 8; }
+IgemmDispatch igemm_last_dispatch() { return g_last; }
+// "igemm<dtype,BM,BN,WM,WN,NST,PIPE,LDR>" + "/splitk" when the launch ran K slices (partial epilogue + finish kernel)
+std::string igemm_dispatch_name(const IgemmDispatch& d) {
+  char buf[96];
+  std::snprintf(buf, sizeof buf, "igemm<%s,%d,%d,%d,%d,%d,%d,%d>%s", d.dtype == DT_BF16 ? "bf16" : "f32", d.bm, d.bn, d.wm, d.wn,
+                d.nst, d.pipe, d.ldr, d.splits > 1 ? "/splitk" : "");
+  return buf;
+}
+void igemm_log_enable(int on) { g_log_on = on != 0; if (on) g_log.clear(); }
+std::string igemm_log_read() {
+  std::string out;
+  for (const auto& e : g_log) { out += e; out += '\n'; }
+  return out;
+}
 
 int igemm_pick_bn(int n_real, int epi) {
   if (epi == EPI_GEGLU) return 128;

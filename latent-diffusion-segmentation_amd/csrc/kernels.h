@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <string>
+
 namespace ldmseg {
 
 enum DType : int { DT_F32 = 0, DT_BF16 = 1 };
@@ -56,7 +58,15 @@ size_t igemm_partial_bytes(const IgemmParams& p);
 int igemm_plan_splits(const IgemmParams& p, int dtype);
 void attention_set_qf1(int v);    // tuning knob: force 16 query rows per wave
 void igemm_set_tsbuf(void* dev_buf);   // LDMSEG_IGEMM_ABLATE builds only
-void igemm_set_dbg(int flags);   // ablation flags (profiling only)   // K-loop ring depth (2, 3, 4) - tuning knob
+void igemm_set_dbg(int flags);
+int igemm_get_dbg();       // current (policy << 8) | ablation flags
+int igemm_default_dbg();   // the shipped value
+// template instantiation + plan of the most recent launch_igemm (test introspection)
+struct IgemmDispatch { int dtype, bm, bn, wm, wn, nst, pipe, ldr, splits, grid; };
+IgemmDispatch igemm_last_dispatch();
+std::string igemm_dispatch_name(const IgemmDispatch& d);
+void igemm_log_enable(int on);      // start (and clear) / stop recording the distinct instantiations launched
+std::string igemm_log_read();       // newline-separated   // ablation flags (profiling only)   // K-loop ring depth (2, 3, 4) - tuning knob
 // tile the launcher would pick (for weight padding): N tile size for a given N.
 int igemm_pick_bn(int n_real, int epi);
 
@@ -116,7 +126,7 @@ int launch_ddim_step(const float* eps, const float* x, float* prev, float* x0, s
 int launch_inpaint_paste(float* cur, const float* z0, const float* noise, const uint8_t* known, float sa, float sb,
                          int B, int C, int HW, hipStream_t s);
 // add_noise / remove_noise with per-sample timesteps (ddim_scheduler.py:155-216)
-int launch_add_noise(const float* x0, const float* noise, const int64_t* t_dev, const float* ac_dev, float scale,
+int launch_add_noise(const float* x0, const float* noise, const int64_t* t_dev, const float* ac_dev, int n_train, float scale,
                      float* out, int B, size_t per, int remove, hipStream_t s);
 // softmax(scale * s) over the last dim of fp32 scores [rows][n] -> probabilities in the compute dtype [rows][n]
 int launch_softmax_rows(const float* s, void* p, int rows, int n, float scale, int dtype, hipStream_t st);

@@ -27,28 +27,46 @@ __device__ __forceinline__ uint4 load_cat(const GNParams& p, int b, int pix, int
   return *(const uint4*)((const T*)p.src1 + ((size_t)b * p.HW + pix) * p.C1 + (c - p.C0));
 }
 
-// fixed-order reduction of one image's per-chunk partials: 8 lanes per group (each a fixed chunk subset, fixed
-// shuffle tree -> deterministic), fp64 for the final mean / variance.  256 threads; out = {mean, rstd} per group.
+// Parallel-variance combination (Chan et al.): (n, mean, M2) <- (n, mean, M2) + (nb, mb, M2b).  Used at every level of
+// the GroupNorm statistics (thread -> workgroup -> image), so the variance never comes from E[x^2] - E[x]^2 and large
+// channel means (real checkpoints) cannot cancel it away.
+__device__ __forceinline__ void chan_add(double& n, double& mean, double& m2, double nb, double mb, double m2b) {
+  if (nb <= 0.0) return;
+  const double tot = n + nb;
+  const double d = mb - mean;
+  mean += d * (nb / tot);
+  m2 += m2b + d * d * (n * nb / tot);
+  n = tot;
+}
+
+// fixed-order reduction of one image's per-chunk partials {mean, M2}: 8 lanes per group (each a fixed chunk subset,
+// fixed shuffle tree -> deterministic), fp64.  256 threads; out = {mean, rstd} per group.
 __device__ __forceinline__ void gn_reduce_stats(const GNParams& p, int b, int cpg, float* out) {
   const int g = threadIdx.x >> 3, sub = threadIdx.x & 7;
-  double s = 0.0, q = 0.0;
+  const int per = (p.HW + p.nchunk - 1) / p.nchunk;
+  double n = 0.0, mean = 0.0, m2 = 0.0;
   if (g < p.groups) {
     for (int ch = sub; ch < p.nchunk; ch += 8) {
+      const int p0 = ch * per, p1 = min(p.HW, p0 + per);
+      if (p1 <= p0) continue;
       const float2 pp = *(const float2*)(p.partial + (((size_t)b * p.nchunk + ch) * p.groups + g) * 2);
-      s += (double)pp.x;
-      q += (double)pp.y;
+      chan_add(n, mean, m2, (double)(p1 - p0) * cpg, (double)pp.x, (double)pp.y);
     }
   }
 #pragma unroll
   for (int o = 4; o > 0; o >>= 1) {
-    s += __shfl_xor(s, o);
-    q += __shfl_xor(q, o);
+    const double nb = __shfl_xor(n, o), mb = __shfl_xor(mean, o), m2b = __shfl_xor(m2, o);
+    // both partners must end up with the same value: combine in a lane-independent order (lower lane first)
+    if (threadIdx.x & o) {
+      double n2 = nb, mean2 = mb, m22 = m2b;
+      chan_add(n2, mean2, m22, n, mean, m2);
+      n = n2; mean = mean2; m2 = m22;
+    } else {
+      chan_add(n, mean, m2, nb, mb, m2b);
+    }
   }
   if (g < p.groups && sub == 0) {
-    const double n = (double)p.HW * cpg;
-    const double mean = s / n;
-    double var = q / n - mean * mean;
-    if (var < 0.0) var = 0.0;
+    const double var = n > 0.0 ? m2 / n : 0.0;
     out[g * 2 + 0] = (float)mean;
     out[g * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.eps));
   }
@@ -69,18 +87,28 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const GNParams p) {
   const int p0 = chunk * per;
   const int p1 = min(p.HW, p0 + per);
 
-  __shared__ float red[kMaxIter][256][4];
+  __shared__ float red[kMaxIter][256][4];   // per thread: {mean, M2} of its low / high group part
 
   const int niter = (nvec + VX - 1) / VX;
   for (int it = 0; it < niter; ++it) {
     const int v = tx + it * VX;
-    float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+    // shifted sums: the shift K is the thread's first sample of each part, so the fp32 accumulators only ever see
+    // deviations of the order of the standard deviation (no cancellation against a large mean)
+    float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f, k0 = 0.f, k1 = 0.f;
+    int npix = 0, split = PC;
     if (ty < TY && v < nvec) {
       const int c0 = v * PC;
       const int g0 = c0 / cpg;
-      const int split = min(PC, (g0 + 1) * cpg - c0);  // elements [0,split) -> g0, rest -> g0+1
-      // four pixels per trip: the loads are issued together, so each thread keeps 64 B in flight
+      split = min(PC, (g0 + 1) * cpg - c0);  // elements [0,split) -> g0, rest -> g0+1
       int pix = p0 + ty;
+      if (pix < p1) {
+        float f[PC];
+        Chunk<T>::unpack(load_cat<T>(p, b, pix, v), f);
+        k0 = f[0];
+#pragma unroll
+        for (int e = 1; e < PC; ++e) if (e == split) k1 = f[e];
+      }
+      // four pixels per trip: the loads are issued together, so each thread keeps 64 B in flight
       for (; pix + 3 * TY < p1; pix += 4 * TY) {
         uint4 raw[4];
 #pragma unroll
@@ -91,10 +119,11 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const GNParams p) {
           Chunk<T>::unpack(raw[u], f);
 #pragma unroll
           for (int e = 0; e < PC; ++e) {
-            if (e < split) { s0 += f[e]; q0 += f[e] * f[e]; }
-            else { s1 += f[e]; q1 += f[e] * f[e]; }
+            if (e < split) { const float d = f[e] - k0; s0 += d; q0 += d * d; }
+            else { const float d = f[e] - k1; s1 += d; q1 += d * d; }
           }
         }
+        npix += 4;
       }
       for (; pix < p1; pix += TY) {
         const uint4 raw = load_cat<T>(p, b, pix, v);
@@ -102,32 +131,45 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const GNParams p) {
         Chunk<T>::unpack(raw, f);
 #pragma unroll
         for (int e = 0; e < PC; ++e) {
-          if (e < split) { s0 += f[e]; q0 += f[e] * f[e]; }
-          else { s1 += f[e]; q1 += f[e] * f[e]; }
+          if (e < split) { const float d = f[e] - k0; s0 += d; q0 += d * d; }
+          else { const float d = f[e] - k1; s1 += d; q1 += d * d; }
         }
+        ++npix;
       }
     }
-    red[it][tid][0] = s0; red[it][tid][1] = q0; red[it][tid][2] = s1; red[it][tid][3] = q1;
+    const float n0 = (float)(npix * split), n1 = (float)(npix * (PC - split));
+    const float ms0 = n0 > 0.f ? s0 / n0 : 0.f, ms1 = n1 > 0.f ? s1 / n1 : 0.f;
+    red[it][tid][0] = k0 + ms0; red[it][tid][1] = fmaxf(q0 - s0 * ms0, 0.f);
+    red[it][tid][2] = k1 + ms1; red[it][tid][3] = fmaxf(q1 - s1 * ms1, 0.f);
   }
   __syncthreads();
-  // fixed-order reduction: thread j -> (group j>>1, stat j&1)
-  if (tid < 2 * p.groups) {
-    const int g = tid >> 1, st = tid & 1;
+  // fixed-order combination: thread g -> group g
+  if (tid < p.groups) {
+    const int g = tid;
     const int c_lo = g * cpg, c_hi = c_lo + cpg - 1;
     // vectors overlapping channels [c_lo, c_hi]: low part feeds g when g0==g, high part when g0+1==g
     const int v_first = max(0, c_lo / PC - 1);
     const int v_last = min(nvec - 1, c_hi / PC);
-    double acc = 0.0;
+    double n = 0.0, mean = 0.0, m2 = 0.0;
     for (int v = v_first; v <= v_last; ++v) {
-      const int g0 = (v * PC) / cpg;
+      const int c0 = v * PC;
+      const int g0 = c0 / cpg;
+      const int split = min(PC, (g0 + 1) * cpg - c0);
       const int it = v / VX, x = v - it * VX;
-      if (g0 == g) {
-        for (int y = 0; y < TY; ++y) acc += (double)red[it][y * VX + x][st];
-      } else if (g0 + 1 == g) {
-        for (int y = 0; y < TY; ++y) acc += (double)red[it][y * VX + x][2 + st];
+      int part, cnt;
+      if (g0 == g) { part = 0; cnt = split; }
+      else if (g0 + 1 == g) { part = 2; cnt = PC - split; }
+      else continue;
+      if (cnt == 0) continue;
+      for (int y = 0; y < TY; ++y) {
+        const int first = p0 + y;
+        const int np = first < p1 ? (p1 - first + TY - 1) / TY : 0;
+        chan_add(n, mean, m2, (double)np * cnt, (double)red[it][y * VX + x][part], (double)red[it][y * VX + x][part + 1]);
       }
     }
-    p.partial[(((size_t)b * p.nchunk + chunk) * p.groups + g) * 2 + st] = (float)acc;
+    float* dst = p.partial + (((size_t)b * p.nchunk + chunk) * p.groups + g) * 2;
+    dst[0] = (float)mean;
+    dst[1] = (float)m2;
   }
 }
 
@@ -300,21 +342,29 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const GNParams p) {
       if constexpr (EPU == 2) { v[k][0] = bits_f32(raw << 16); v[k][1] = bits_f32(raw & 0xffff0000u); }
       else { v[k][0] = bits_f32(raw); }
 #pragma unroll
-      for (int e = 0; e < EPU; ++e) { s += v[k][e]; q += v[k][e] * v[k][e]; }
+      for (int e = 0; e < EPU; ++e) s += v[k][e];
     }
   }
+  // two passes over the register-resident values: mean first, then the centred second moment (torch's arithmetic)
   __shared__ float red[2][4];
   s = wave64_sum(s);
-  q = wave64_sum(q);
-  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = q; }
+  if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = s;
   __syncthreads();
-  const double st = (double)red[0][0] + (double)red[0][1] + (double)red[0][2] + (double)red[0][3];
-  const double qt = (double)red[1][0] + (double)red[1][1] + (double)red[1][2] + (double)red[1][3];
   const double n = (double)p.HW * cpg;
-  const double mean_d = st / n;
-  double var = qt / n - mean_d * mean_d;
-  if (var < 0.0) var = 0.0;
-  const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(var + (double)p.eps));
+  const float mean = (float)(((double)red[0][0] + (double)red[0][1] + (double)red[0][2] + (double)red[0][3]) / n);
+  q = 0.f;
+#pragma unroll
+  for (int k = 0; k < MAXU; ++k) {
+    if (threadIdx.x + k * 256 < nunits) {
+#pragma unroll
+      for (int e = 0; e < EPU; ++e) { const float d = v[k][e] - mean; q += d * d; }
+    }
+  }
+  q = wave64_sum(q);
+  if ((threadIdx.x & 63) == 0) red[1][threadIdx.x >> 6] = q;
+  __syncthreads();
+  const double var = ((double)red[1][0] + (double)red[1][1] + (double)red[1][2] + (double)red[1][3]) / n;
+  const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
 #pragma unroll
   for (int k = 0; k < MAXU; ++k) {
     const int u = threadIdx.x + k * 256;
@@ -365,35 +415,50 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const GNParams p, int GB)
     const int pix = pr + ppi * k;
     raw[k] = (active && pix < p.HW) ? *(const u32x4*)(src + (size_t)pix * cs) : u32x4{0u, 0u, 0u, 0u};
   }
-  float slo = 0.f, qlo = 0.f, shi = 0.f, qhi = 0.f;
+  // pass 1: group sums -> means; pass 2: centred second moments of the register-resident values
+  float slo = 0.f, shi = 0.f;
 #pragma unroll
   for (int k = 0; k < MAXV; ++k) {
 #pragma unroll
     for (int e = 0; e < PC; ++e) {
       const float f = to_f32<T>(chunk_elem<T>(raw[k], e));     // out-of-range vectors are zero: they add nothing
-      if (e < split) { slo += f; qlo += f * f; }
-      else { shi += f; qhi += f * f; }
+      if (e < split) slo += f;
+      else shi += f;
     }
   }
   // block-local group sums: group 0 gets the low part of glo == 0 vectors, group 1 the rest
-  float v[4] = {glo == 0 ? slo : 0.f, glo == 0 ? qlo : 0.f, glo == 0 ? shi : slo, glo == 0 ? qhi : qlo};
   __shared__ float red[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    v[i] = wave64_sum(v[i]);
-    if ((tid & 63) == 0) red[i][tid >> 6] = v[i];
+  {
+    float v0 = wave64_sum(glo == 0 ? slo : 0.f), v1 = wave64_sum(glo == 0 ? shi : slo);
+    if ((tid & 63) == 0) { red[0][tid >> 6] = v0; red[1][tid >> 6] = v1; }
   }
   __syncthreads();
   const double n = (double)p.HW * cpg;
   float mean[2], rstd[2];
 #pragma unroll
+  for (int g = 0; g < 2; ++g)
+    mean[g] = (float)(((double)red[g][0] + (double)red[g][1] + (double)red[g][2] + (double)red[g][3]) / n);
+  {
+    const float mlo = glo == 0 ? mean[0] : mean[1], mhi = mean[1];
+    float qlo = 0.f, qhi = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      if (active && pr + ppi * k < p.HW) {
+#pragma unroll
+        for (int e = 0; e < PC; ++e) {
+          const float f = to_f32<T>(chunk_elem<T>(raw[k], e));
+          if (e < split) { const float d = f - mlo; qlo += d * d; }
+          else { const float d = f - mhi; qhi += d * d; }
+        }
+      }
+    }
+    float v0 = wave64_sum(glo == 0 ? qlo : 0.f), v1 = wave64_sum(glo == 0 ? qhi : qlo);
+    if ((tid & 63) == 0) { red[2][tid >> 6] = v0; red[3][tid >> 6] = v1; }
+  }
+  __syncthreads();
+#pragma unroll
   for (int g = 0; g < 2; ++g) {
-    const double st = (double)red[2 * g][0] + (double)red[2 * g][1] + (double)red[2 * g][2] + (double)red[2 * g][3];
-    const double qt = (double)red[2 * g + 1][0] + (double)red[2 * g + 1][1] + (double)red[2 * g + 1][2] + (double)red[2 * g + 1][3];
-    const double m = st / n;
-    double var = qt / n - m * m;
-    if (var < 0.0) var = 0.0;
-    mean[g] = (float)m;
+    const double var = ((double)red[2 + g][0] + (double)red[2 + g][1] + (double)red[2 + g][2] + (double)red[2 + g][3]) / n;
     rstd[g] = (float)(1.0 / sqrt(var + (double)p.eps));
   }
   if (!active) return;

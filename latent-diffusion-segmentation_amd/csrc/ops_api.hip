@@ -240,4 +240,72 @@ int ldmseg_op_bilinear2x(const float* x, int B, int C, int H, int W, int dtype, 
   return launch_bilinear2x_nchw(xp, out, B, H, W, C, dtype, s);
 }
 
+// The engine's launch of one conv / GEMM layer, exactly as engine.hip issues it in a forward: NHWC operands in the compute
+// dtype, the split-K plan of igemm_plan_splits (splits = 0) or a forced one, the row-major store epilogue with optional
+// bias, per-image bias row (time embedding), residual and SiLU, or the GEGLU epilogue.  Boundary tensors are NCHW f32:
+// x [B,Ci,H,W], x2 [B,Ci2,H,W] or NULL, w [Co,Ci+Ci2,k,k], resid [B,Cout,Ho,Wo] or NULL, rowbias [B,Co] or NULL,
+// out [B,Cout,Ho,Wo] with Cout = Co (Co/2 for GEGLU, whose w rows are [value | gate] like ff.net.0.proj).
+int ldmseg_op_igemm(const float* x, const float* x2, const float* w, const float* bias, const float* resid,
+                    const float* rowbias, int B, int Ci, int Ci2, int H, int W, int Co, int k, int stride, int up, int geglu,
+                    int silu, int splits, int dtype, float* out, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  Temp t;
+  const int a = bke(dtype);
+  const int c0 = rupi(Ci, a), c1 = Ci2 ? rupi(Ci2, a) : 0;
+  if (Ci2 && (Ci % a)) return -2;
+  if (geglu && (k != 1 || Ci2 || (Co % 32))) return -2;
+  void* xp = t.get((size_t)B * H * W * c0 * es(dtype));
+  void* x2p = Ci2 ? t.get((size_t)B * H * W * c1 * es(dtype)) : nullptr;
+  if (launch_pack_nchw(x, xp, B, Ci, H * W, c0, 1.f, 0.f, dtype, s)) return -3;
+  if (Ci2 && launch_pack_nchw(x2, x2p, B, Ci2, H * W, c1, 1.f, 0.f, dtype, s)) return -3;
+  const int epi = geglu ? EPI_GEGLU : EPI_STORE;
+  const int bn = igemm_pick_bn(Co, epi);
+  const int Np = rupi(Co, bn);
+  const int ct = c0 + c1;
+  const int cout = geglu ? Co / 2 : Co;
+  void* wp = t.get((size_t)Np * k * k * ct * es(dtype));
+  float* bp = (float*)t.get(Np * sizeof(float));
+  (void)hipMemsetAsync(bp, 0, Np * sizeof(float), s);
+  if (geglu) {
+    std::vector<int> map(Np);
+    for (int r = 0; r < Np; ++r) {
+      const int blk = r / 32, q = r % 32;
+      map[r] = (q < 16) ? blk * 16 + q : cout + blk * 16 + (q - 16);
+    }
+    int* dmap = (int*)t.get(Np * sizeof(int));
+    (void)hipMemcpy(dmap, map.data(), Np * sizeof(int), hipMemcpyHostToDevice);
+    if (launch_repack_rows(w, wp, dmap, Np, ct, dtype, s)) return -3;
+    if (bias && launch_repack_rows(bias, bp, dmap, Np, 1, DT_F32, s)) return -3;
+  } else if (!Ci2) {
+    if (launch_repack_conv(w, wp, Co, Ci, k, k, Np, c0, dtype, s)) return -3;
+    if (bias) (void)hipMemcpyAsync(bp, bias, Co * sizeof(float), hipMemcpyDeviceToDevice, s);
+  } else {
+    void* w_cat = t.get((size_t)Co * ct * k * k * sizeof(float));
+    (void)hipMemsetAsync(w_cat, 0, (size_t)Co * ct * k * k * sizeof(float), s);
+    (void)hipMemcpy2DAsync(w_cat, (size_t)ct * k * k * sizeof(float), w, (size_t)(Ci + Ci2) * k * k * sizeof(float),
+                           (size_t)(Ci + Ci2) * k * k * sizeof(float), Co, hipMemcpyDeviceToDevice, s);
+    if (launch_repack_conv((const float*)w_cat, wp, Co, ct, k, k, Np, ct, dtype, s)) return -3;
+    if (bias) (void)hipMemcpyAsync(bp, bias, Co * sizeof(float), hipMemcpyDeviceToDevice, s);
+  }
+  const int Hl = up ? 2 * H : H, Wl = up ? 2 * W : W;
+  const int Ho = (k == 3 && stride == 2) ? (Hl - 1) / 2 + 1 : Hl, Wo = (k == 3 && stride == 2) ? (Wl - 1) / 2 + 1 : Wl;
+  void* rp = nullptr;
+  if (resid) {
+    rp = t.get((size_t)B * Ho * Wo * cout * es(dtype));
+    if (launch_pack_nchw(resid, rp, B, cout, Ho * Wo, cout, 1.f, 0.f, dtype, s)) return -3;
+  }
+  void* op = t.get((size_t)B * Ho * Wo * cout * es(dtype));
+  IgemmParams p;
+  p.src0 = xp; p.C0 = c0; p.src1 = x2p; p.C1 = c1;
+  p.B = B; p.Hi = H; p.Wi = W; p.Ho = Ho; p.Wo = Wo; p.taps = k * k; p.stride = stride; p.up = up;
+  p.M = B * Ho * Wo; p.N = Np; p.n_valid = cout; p.W = wp; p.bias = bp;
+  p.rowbias = rowbias; p.rb_stride = Co;
+  p.resid = rp; p.ldr = cout; p.out = op; p.ldo = cout; p.epi = epi; p.silu = silu;
+  int sp = splits > 0 ? splits : igemm_plan_splits(p, dtype);
+  if (sp > 1) { p.splits = sp; p.partial = (float*)t.get((size_t)sp * p.M * Np * sizeof(float)); }
+  const int r = launch_igemm(p, dtype, s);
+  if (r) return r;
+  return unpack_nhwc(op, out, B, cout, Ho * Wo, cout, dtype, s);
+}
+
 }  // extern "C"

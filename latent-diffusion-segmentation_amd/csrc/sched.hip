@@ -53,12 +53,16 @@ __global__ void inpaint_paste_kernel(float* cur, const float* z0, const float* n
   }
 }
 
-__global__ void add_noise_kernel(const float* x0, const float* noise, const int64_t* t, const float* ac, float scale,
-                                 float* out, size_t per, size_t total, int remove) {
+// timesteps outside [0, n_train) would be an IndexError in the reference (ddim_scheduler.py:170); the host wrapper
+// rejects them when it can see them, the kernel clamps so that a bad device-resident index can never read out of bounds
+__global__ void add_noise_kernel(const float* x0, const float* noise, const int64_t* t, const float* ac, int n_train,
+                                 float scale, float* out, size_t per, size_t total, int remove) {
 #pragma clang fp contract(off)
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const size_t b = i / per;
-    const float a = ac[t[b]];
+    int64_t tb = t[b];
+    tb = tb < 0 ? 0 : (tb >= n_train ? n_train - 1 : tb);
+    const float a = ac[tb];
     const float sa = __fsqrt_rn(a), sb = __fsqrt_rn(__fsub_rn(1.0f, a));
     if (!remove) out[i] = __fadd_rn(__fmul_rn(__fmul_rn(sa, scale), x0[i]), __fmul_rn(sb, noise[i]));
     else out[i] = __fdiv_rn(__fsub_rn(x0[i], __fmul_rn(sb, noise[i])), __fmul_rn(sa, scale));
@@ -85,10 +89,10 @@ int launch_inpaint_paste(float* cur, const float* z0, const float* noise, const 
   return ok();
 }
 
-int launch_add_noise(const float* x0, const float* noise, const int64_t* t_dev, const float* ac_dev, float scale,
+int launch_add_noise(const float* x0, const float* noise, const int64_t* t_dev, const float* ac_dev, int n_train, float scale,
                      float* out, int B, size_t per, int remove, hipStream_t s) {
   const size_t total = (size_t)B * per;
-  hipLaunchKernelGGL(add_noise_kernel, dim3(grid_for(total)), dim3(256), 0, s, x0, noise, t_dev, ac_dev, scale, out, per, total, remove);
+  hipLaunchKernelGGL(add_noise_kernel, dim3(grid_for(total)), dim3(256), 0, s, x0, noise, t_dev, ac_dev, n_train, scale, out, per, total, remove);
   return ok();
 }
 

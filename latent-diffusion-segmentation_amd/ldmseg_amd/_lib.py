@@ -57,8 +57,9 @@ SIGNATURES = {
     "ldmseg_vae_posterior": (_i, [_vp, _vp, _f, _i, _i, _vp, _vp]),
     "ldmseg_vae_num_params": (_i64, [_vp]),
     "ldmseg_ddim_step": (_i, [_vp, _vp, _f, _f, _f, _f, _i, _i, _f, _i, _vp, _vp, _sz, _vp]),
-    "ldmseg_add_noise": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _i, _sz, _vp]),
-    "ldmseg_remove_noise": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _i, _sz, _vp]),
+    "ldmseg_add_noise": (_i, [_vp, _vp, _vp, _vp, _i, _f, _vp, _i, _sz, _vp]),
+    "ldmseg_remove_noise": (_i, [_vp, _vp, _vp, _vp, _i, _f, _vp, _i, _sz, _vp]),
+    "ldmseg_unet_reserve": (_i, [_vp, _i, _i]),
     "ldmseg_sample_loop": (_i, [_vp, C.POINTER(SampleCfg), _vp, _vp, _i, _i, _vp, _vp]),
     "ldmseg_vae_image_create": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
     "ldmseg_vae_image_destroy": (None, [_vp]),
@@ -74,6 +75,7 @@ SIGNATURES = {
     "ldmseg_profile_reset": (_i, []),
     "ldmseg_profile_dump": (_i, [C.c_char_p]),
     "ldmseg_debug_set": (_i, [_i, _i]),
+    "ldmseg_debug_get": (_i, [_i]),
     # include/ldmseg_hip_ops.h
     "ldmseg_op_conv2d": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "ldmseg_op_linear": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
@@ -82,6 +84,10 @@ SIGNATURES = {
     "ldmseg_op_attention": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "ldmseg_op_convt2": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "ldmseg_op_bilinear2x": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "ldmseg_op_igemm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "ldmseg_igemm_last_kernel": (_i, [C.c_char_p, _i]),
+    "ldmseg_igemm_log": (_i, [_i]),
+    "ldmseg_igemm_log_read": (_i, [C.c_char_p, _i]),
 }
 
 _lib = None
@@ -108,6 +114,24 @@ def check(code, what=""):
     if code != 0:
         msg = lib().ldmseg_last_error()
         raise RuntimeError(f"libldmseg_hip: {what} failed with code {code}: {msg.decode() if msg else ''}")
+
+
+def igemm_last_kernel():
+    """Instantiation + plan of the most recent igemm launch, e.g. 'igemm<bf16,256,160,4,2,3,1,0> splits=1 grid=256'."""
+    buf = C.create_string_buffer(128)
+    lib().ldmseg_igemm_last_kernel(buf, 128)
+    return buf.value.decode()
+
+
+def igemm_log(enable):
+    lib().ldmseg_igemm_log(1 if enable else 0)
+
+
+def igemm_log_read():
+    """Set of distinct igemm instantiations launched since igemm_log(True)."""
+    buf = C.create_string_buffer(1 << 16)
+    check(lib().ldmseg_igemm_log_read(buf, 1 << 16), "ldmseg_igemm_log_read")
+    return {ln for ln in buf.value.decode().split("\n") if ln}
 
 
 def stream_ptr(device=None):

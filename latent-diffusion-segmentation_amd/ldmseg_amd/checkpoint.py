@@ -46,14 +46,23 @@ def vae_state_from(data: dict) -> "OrderedDict[str, torch.Tensor]":
     return OrderedDict((k, sd[k]) for k in schema)
 
 
+def _load(path: str):
+    """Tensors-only unpickling first; the reference's checkpoints also pickle the config dict `p` (plain python
+    containers, fine) and, in some runs, optimizer / scaler objects - only those fall back to the full unpickler."""
+    try:
+        return torch.load(path, map_location="cpu", weights_only=True)
+    except Exception:
+        return torch.load(path, map_location="cpu", weights_only=False)
+
+
 def load_ldm_checkpoint(path: str, use_ema: bool = False):
-    data = torch.load(path, map_location="cpu", weights_only=False)
+    data = _load(path)
     return {"unet": unet_state_from(data, use_ema), "vae_semseg": vae_state_from(data) if "vae_semseg" in data else None,
             "p": data.get("p"), "step": data.get("step"), "epoch": data.get("epoch")}
 
 
 def load_ae_checkpoint(path: str):
-    data = torch.load(path, map_location="cpu", weights_only=False)
+    data = _load(path)
     return vae_state_from(data)
 
 

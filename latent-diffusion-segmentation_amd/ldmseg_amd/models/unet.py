@@ -63,6 +63,13 @@ class UNet(object):
     def workspace_bytes(self, batch: int, latent_size: int) -> int:
         return int(_lib.lib().ldmseg_unet_workspace_bytes(self._h, batch, latent_size))
 
+    def reserve(self, batch: int, latent_size: int):
+        """Allocate the forward / sampling workspaces for (batch, latent_size) now, so that later calls at that size
+        never allocate or synchronise (ldmseg_unet_reserve)."""
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().ldmseg_unet_reserve(self._h, int(batch), int(latent_size)), "ldmseg_unet_reserve")
+        return self
+
     def eval(self):
         return self
 

@@ -49,7 +49,7 @@ class DDIMNoiseScheduler(object):
         self.final_alpha_cumprod = self.alphas_cumprod[0] if not set_alpha_to_one else torch.tensor(1.0)
         self.compute_loss_weights(mode=weight, max_snr=max_snr)
         self.weights = self.weights.to(device)
-        self.timesteps = torch.arange(T - 1, -1, -1, dtype=torch.int64)   # default grid 999..0
+        self._install_timesteps(torch.arange(T - 1, -1, -1, dtype=torch.int64), list(range(T - 1, -1, -1)))   # 999..0
         self.num_train_timesteps = T
         self.num_inference_steps = None
         self.init_noise_sigma = 1.0
@@ -59,8 +59,27 @@ class DDIMNoiseScheduler(object):
                             ("steps_offset", steps_offset), ("beta_schedule", beta_schedule),
                             ("beta_start", beta_start), ("beta_end", beta_end), ("verbose", verbose)):
             setattr(self, name, value)
-        self._timesteps_host = None     # python ints of self.timesteps (no sync needed later)
         self._ac_dev = {}               # device -> alphas_cumprod copy for add/remove_noise
+
+    # `timesteps` is a property: the host copy (python ints, so that `step` needs no D2H sync) is only trusted while
+    # the tensor it was built from is still the one installed.  Assigning `scheduler.timesteps = something` (e.g. a
+    # slice for partial denoising) drops the cache; it is rebuilt from the tensor on first use.
+    @property
+    def timesteps(self):
+        return self._timesteps
+
+    @timesteps.setter
+    def timesteps(self, value):
+        self._install_timesteps(value, None)
+
+    @staticmethod
+    def _tensor_key(t):
+        return (t.untyped_storage().data_ptr(), t.storage_offset(), tuple(t.shape), str(t.device))
+
+    def _install_timesteps(self, tensor, host_list):
+        self._timesteps = tensor
+        self._timesteps_host = host_list
+        self._timesteps_key = self._tensor_key(tensor) if isinstance(tensor, torch.Tensor) else None
 
     # ------------------------------------------------------------------ host logic
     def compute_loss_weights(self, mode='max_clamp_snr', max_snr=5.0):
@@ -88,11 +107,16 @@ class DDIMNoiseScheduler(object):
         timesteps = (np.arange(0, num_inference_steps) * step_ratio).round()[::-1].copy().astype(np.int64)
         timesteps = timesteps + self.steps_offset
         timesteps = timesteps[timesteps >= tmin]
-        self._timesteps_host = [int(t) for t in timesteps]
-        self.timesteps = torch.from_numpy(timesteps).to(device)
+        self._install_timesteps(torch.from_numpy(timesteps).to(device), [int(t) for t in timesteps])
 
     def move_timesteps_to(self, device: Union[str, torch.device]):
-        self.timesteps = self.timesteps.to(device)
+        host = self._timesteps_host if self._cache_valid() else None
+        self._install_timesteps(self._timesteps.to(device), host)
+
+    def _cache_valid(self) -> bool:
+        t = self._timesteps
+        return (self._timesteps_host is not None and isinstance(t, torch.Tensor)
+                and self._timesteps_key == self._tensor_key(t) and len(self._timesteps_host) == t.numel())
 
     def get_betas_for_alpha_bar(self, num_diffusion_timesteps, max_beta=0.999) -> torch.Tensor:
         """Glide cosine schedule: beta_i = min(1 - abar((i+1)/T) / abar(i/T), max_beta)."""
@@ -113,16 +137,18 @@ class DDIMNoiseScheduler(object):
 
     def timesteps_host(self):
         """`self.timesteps` as python ints without touching the device."""
-        if self._timesteps_host is None or len(self._timesteps_host) != len(self.timesteps):
-            self._timesteps_host = [int(t) for t in self.timesteps.cpu()]
+        if not self._cache_valid():
+            t = self._timesteps
+            self._install_timesteps(t, [int(v) for v in torch.as_tensor(t).reshape(-1).cpu()])
         return self._timesteps_host
 
     def _timestep_int(self, timestep) -> int:
         if isinstance(timestep, torch.Tensor):
-            if timestep.is_cuda and self._timesteps_host is not None:
-                # the common case: `for t in scheduler.timesteps` - match by identity of storage offset
-                base = self.timesteps
-                if (base.is_cuda and timestep.dim() == 0
+            if timestep.is_cuda and self._cache_valid():
+                # the common case: `for t in scheduler.timesteps` - an element view of the installed tensor is
+                # resolved through the host copy by its storage offset (valid only while that tensor is installed)
+                base = self._timesteps
+                if (base.is_cuda and base.dim() == 1 and base.is_contiguous() and timestep.dim() == 0
                         and timestep.untyped_storage().data_ptr() == base.untyped_storage().data_ptr()):
                     idx = timestep.storage_offset() - base.storage_offset()
                     if 0 <= idx < len(self._timesteps_host):
@@ -154,7 +180,13 @@ class DDIMNoiseScheduler(object):
     def _noise_op(self, fn_name, a, noise, timesteps, scale):
         a = _lib.require_cuda_f32(a, "samples")
         noise = _lib.require_cuda_f32(noise, "noise")
+        timesteps = torch.as_tensor(timesteps)
+        if not timesteps.is_cuda and timesteps.numel() and (
+                int(timesteps.min()) < -self.num_train_timesteps or int(timesteps.max()) >= self.num_train_timesteps):
+            raise IndexError(f"timestep out of range for a table of {self.num_train_timesteps} entries")   # as the reference's table lookup
         t = timesteps.to(device=a.device, dtype=torch.int64).contiguous().flatten()
+        if not timesteps.is_cuda:
+            t = torch.where(t < 0, t + self.num_train_timesteps, t)      # python-style negative indices, like tensor[t]
         B = a.shape[0]
         if t.numel() == 1 and B > 1:
             t = t.expand(B).contiguous()
@@ -163,8 +195,9 @@ class DDIMNoiseScheduler(object):
         out = torch.empty_like(a)
         with torch.cuda.device(a.device):
             fn = getattr(_lib.lib(), fn_name)
-            _lib.check(fn(_lib.ptr(a), _lib.ptr(noise), _lib.ptr(t), _lib.ptr(self._ac_on(a.device)), float(scale),
-                          _lib.ptr(out), B, a.numel() // B, _lib.stream_ptr(a.device)), fn_name)
+            _lib.check(fn(_lib.ptr(a), _lib.ptr(noise), _lib.ptr(t), _lib.ptr(self._ac_on(a.device)),
+                          int(self.num_train_timesteps), float(scale), _lib.ptr(out), B, a.numel() // B,
+                          _lib.stream_ptr(a.device)), fn_name)
         return out
 
     def add_noise(self, original_samples, noise, timesteps, scale: float = 1.0, mask_noise_perc: Optional[float] = None):

@@ -204,14 +204,21 @@ class TrainerDiffusion(object):
     @torch.no_grad()
     def decode_latents(self, latents: torch.Tensor, return_logits: bool = False, threshold_output: bool = False,
                        rgb_latents=None, weight_dtype: torch.dtype = torch.float32, mask_th: float = 0.5,
-                       ignore_label: int = 0):
-        """:397-442.  The 1/scaling_factor multiply is fused into the decoder's input packing."""
+                       ignore_label: int = 0, return_ids: bool = False):
+        """:397-442.  return_logits=True -> fp32 logits [B,128,8L,8L] on the GPU; otherwise, like the reference, the
+        colour-encoded uint8 numpy image [B,8L,8L,3] of the argmax ids (`encode_seg`, :436).  `return_ids=True`
+        (extension) returns the int64 id map on the GPU instead of painting it.  The 1/scaling_factor multiply is
+        fused into the decoder's input packing, and argmax (+ max-softmax threshold) with the decoder tail: the
+        logits are never materialised on that path."""
         zs = 1.0 / self.vae_semseg.scaling_factor
         if return_logits:
             return self.vae_semseg.decode(latents, z_scale=zs).float()
-        # argmax (+ max-softmax threshold) fused with the decoder tail: the logits are never materialised
-        return self.vae_semseg.decode_argmax(latents, z_scale=zs, mask_th=mask_th if threshold_output else None,
-                                             ignore_label=ignore_label)
+        ids = self.vae_semseg.decode_argmax(latents, z_scale=zs, mask_th=mask_th if threshold_output else None,
+                                            ignore_label=ignore_label)
+        if return_ids:
+            return ids
+        from ..utils import encode_seg
+        return encode_seg(ids.cpu().numpy()).astype(np.uint8)
 
     @torch.no_grad()
     def postprocess_panoptic(self, masks_logits: torch.Tensor, threshold_output: bool = False,

@@ -206,6 +206,22 @@ def bitcodec_golden():
     print("bitcodec.npz ok", bits.shape, dec.dtype)
 
 
+def colormap_golden():
+    """color_map() (ldmseg/utils/utils.py:240-258) and TrainerDiffusion.encode_seg (trainers_ldm_cond.py:324-332; the
+    method body only needs numpy + color_map, so it is exercised through the same lookup the method performs)."""
+    from ldmseg.utils.utils import color_map
+    cmap = color_map()
+    g = np.random.RandomState(3)
+    ids = g.randint(0, 256, size=(2, 9, 11)).astype(np.int64)
+    seg_t = ids.astype(np.uint8)
+    painted = np.empty(seg_t.shape + (3,), dtype=cmap.dtype)
+    for c in np.unique(seg_t):
+        painted[seg_t == c] = cmap[c]
+    np.savez_compressed(os.path.join(HERE, "colormap.npz"), cmap=cmap, cmap_norm=color_map(normalized=True).astype(np.float32),
+                        ids=ids, painted=painted)
+    print("colormap.npz ok", cmap.shape, cmap.dtype)
+
+
 def main():
     if not os.path.isdir(REF):
         print("reference not present; nothing to do")
@@ -218,6 +234,7 @@ def main():
     scheduler_golden(DDIMNoiseScheduler)
     vae_golden(GeneralVAESeg)
     loop_golden(DDIMNoiseScheduler)
+    colormap_golden()
     try:
         bitcodec_golden()
     except Exception as e:   # the dataset module drags in many optional deps

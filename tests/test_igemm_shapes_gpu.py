@@ -1,0 +1,175 @@
+"""Parity of the SHIPPED implicit-GEMM instantiations at the real UNet launch shapes (B = 8, 512x512 images).
+
+Every distinct conv / Linear / GEGLU launch shape of a batch-8, L = 64 UNet forward is launched through
+``ldmseg_op_igemm`` - the engine's own launch path: NHWC operands, the engine's split-K plan, the row-major store /
+GEGLU epilogues, residual and time-embedding bias rows - in bf16 and fp32 under the shipped tile policy, and compared
+with the torch-CPU op the reference executes there (F.conv2d / F.linear / GEGLU of diffusers 0.16.1).
+Each test records which template instantiation ran; the last test runs full-size forwards with the dispatch log on and
+fails if the forward used an instantiation that no per-layer oracle comparison above has exercised.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+F32, BF16 = 0, 1
+B = 8
+SEEN = {F32: set(), BF16: set()}
+
+
+@pytest.fixture(scope="module")
+def L():
+    from ldmseg_amd import _lib
+    assert _lib.lib().ldmseg_debug_get(1) == _lib.lib().ldmseg_debug_get(-1), "a previous test leaked a tile policy"
+    return _lib
+
+
+def bf16_round(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def dev(t):
+    return t.to("cuda", torch.float32).contiguous() if t is not None else None
+
+
+def P(t):
+    import ctypes as C
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+# (H, Ci, Ci2, Co, k, stride, up, geglu, resid, rowbias)  -  H = input side; all at batch 8
+SHAPES = [
+    # ---- 64x64 maps (M = 32768)
+    (64, 320, 0, 320, 3, 1, 0, 0, 0, 1),      # resnet conv1 (+ time-embedding row)
+    (64, 320, 0, 320, 3, 1, 0, 0, 1, 0),      # resnet conv2 (+ residual)
+    (64, 320, 320, 320, 3, 1, 0, 0, 0, 1),    # up-path conv1 on cat([h, skip])
+    (64, 640, 320, 320, 3, 1, 0, 0, 0, 1),
+    (64, 12, 0, 320, 3, 1, 0, 0, 0, 0),       # conv_in
+    (64, 320, 0, 320, 1, 1, 0, 0, 1, 0),      # proj_out / to_out (+ residual)
+    (64, 320, 0, 320, 1, 1, 0, 0, 0, 0),      # proj_in
+    (64, 320, 0, 960, 1, 1, 0, 0, 0, 0),      # fused q|k|v
+    (64, 320, 0, 2560, 1, 1, 0, 1, 0, 0),     # GEGLU
+    (64, 1280, 0, 320, 1, 1, 0, 0, 1, 0),     # ff.net.2 (+ residual)
+    (64, 320, 320, 320, 1, 1, 0, 0, 0, 0),    # conv_shortcut on a concat
+    (64, 640, 320, 320, 1, 1, 0, 0, 0, 0),
+    (32, 640, 0, 640, 3, 1, 1, 0, 0, 0),      # upsampler conv: nearest x2 folded into the gather (M = 32768)
+    (64, 320, 0, 320, 3, 2, 0, 0, 0, 0),      # downsampler conv, stride 2 (M = 8192)
+    # ---- 32x32 maps (M = 8192)
+    (32, 640, 0, 640, 3, 1, 0, 0, 0, 1),
+    (32, 640, 0, 640, 3, 1, 0, 0, 1, 0),
+    (32, 320, 0, 640, 3, 1, 0, 0, 0, 1),
+    (32, 640, 640, 640, 3, 1, 0, 0, 0, 1),
+    (32, 1280, 640, 640, 3, 1, 0, 0, 0, 1),
+    (32, 640, 320, 640, 3, 1, 0, 0, 0, 1),
+    (32, 640, 0, 640, 1, 1, 0, 0, 1, 0),
+    (32, 640, 0, 1920, 1, 1, 0, 0, 0, 0),
+    (32, 640, 0, 5120, 1, 1, 0, 1, 0, 0),
+    (32, 2560, 0, 640, 1, 1, 0, 0, 1, 0),
+    (32, 320, 0, 640, 1, 1, 0, 0, 0, 0),
+    (32, 1280, 640, 640, 1, 1, 0, 0, 0, 0),
+    (32, 640, 640, 640, 1, 1, 0, 0, 0, 0),
+    (32, 640, 320, 640, 1, 1, 0, 0, 0, 0),
+    (16, 1280, 0, 1280, 3, 1, 1, 0, 0, 0),    # upsampler conv 16 -> 32 (M = 8192)
+    (32, 640, 0, 640, 3, 2, 0, 0, 0, 0),      # downsampler (M = 2048)
+    # ---- 16x16 maps (M = 2048)
+    (16, 1280, 0, 1280, 3, 1, 0, 0, 0, 1),
+    (16, 1280, 0, 1280, 3, 1, 0, 0, 1, 0),
+    (16, 640, 0, 1280, 3, 1, 0, 0, 0, 1),
+    (16, 1280, 1280, 1280, 3, 1, 0, 0, 0, 1),
+    (16, 1280, 640, 1280, 3, 1, 0, 0, 0, 1),
+    (16, 1280, 0, 1280, 1, 1, 0, 0, 1, 0),
+    (16, 1280, 0, 3840, 1, 1, 0, 0, 0, 0),
+    (16, 1280, 0, 10240, 1, 1, 0, 1, 0, 0),
+    (16, 5120, 0, 1280, 1, 1, 0, 0, 1, 0),
+    (16, 640, 0, 1280, 1, 1, 0, 0, 0, 0),
+    (16, 1280, 1280, 1280, 1, 1, 0, 0, 0, 0),
+    (16, 1280, 640, 1280, 1, 1, 0, 0, 0, 0),
+    (8, 1280, 0, 1280, 3, 1, 1, 0, 0, 0),     # upsampler conv 8 -> 16 (M = 2048)
+    (16, 1280, 0, 1280, 3, 2, 0, 0, 0, 0),    # downsampler (M = 512)
+    # ---- 8x8 maps (M = 512)
+    (8, 1280, 0, 1280, 3, 1, 0, 0, 0, 1),
+    (8, 1280, 0, 1280, 3, 1, 0, 0, 1, 0),
+    (8, 1280, 1280, 1280, 3, 1, 0, 0, 0, 1),
+    (8, 1280, 0, 1280, 1, 1, 0, 0, 1, 0),
+    (8, 1280, 0, 3840, 1, 1, 0, 0, 0, 0),
+    (8, 1280, 0, 10240, 1, 1, 0, 1, 0, 0),
+    (8, 5120, 0, 1280, 1, 1, 0, 0, 1, 0),
+    (8, 1280, 1280, 1280, 1, 1, 0, 0, 0, 0),
+]
+
+
+@pytest.mark.parametrize("dt", [BF16, F32])
+@pytest.mark.parametrize("case", SHAPES)
+def test_unet_layer_shape_vs_oracle(L, dt, case):
+    H, Ci, Ci2, Co, k, stride, up, geglu, use_res, use_rb = case
+    torch.set_num_threads(32)
+    g = torch.Generator().manual_seed(hash(case) & 0xffff)
+    ct = Ci + Ci2
+    x = torch.randn(B, Ci, H, H, generator=g)
+    x2 = torch.randn(B, Ci2, H, H, generator=g) if Ci2 else None
+    w = torch.randn(Co, ct, k, k, generator=g) / (ct * k * k) ** 0.5
+    b = torch.randn(Co, generator=g)
+    rb = torch.randn(B, Co, generator=g) if use_rb else None
+    xin = torch.cat([x, x2], 1) if Ci2 else x
+    xin_r, w_r = (bf16_round(xin), bf16_round(w)) if dt == BF16 else (xin, w)
+    if up:
+        xin_r = F.interpolate(xin_r, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(xin_r, w_r, b, stride=stride, padding=k // 2)
+    if rb is not None:
+        ref = ref + rb[:, :, None, None]
+    if geglu:
+        a, gate = ref.chunk(2, 1)
+        ref = a * F.gelu(gate)
+    res = torch.randn(ref.shape, generator=g) if use_res else None
+    if res is not None:
+        ref = ref + (bf16_round(res) if dt == BF16 else res)
+    out = torch.empty(ref.shape, device="cuda")
+    dx, dx2, dw, db, dres, drb = dev(x), dev(x2), dev(w), dev(b), dev(res), dev(rb)
+    r = L.lib().ldmseg_op_igemm(P(dx), P(dx2), P(dw), P(db), P(dres), P(drb), B, Ci, Ci2, H, H, Co, k, stride, up, geglu,
+                                0, 0, dt, P(out), None)
+    assert r == 0, L.lib().ldmseg_last_error()
+    torch.cuda.synchronize()
+    name = L.igemm_last_kernel()
+    SEEN[dt].add(name.split(" ")[0])
+    # bf16: operands rounded identically, the difference is accumulation order + the bf16 rounding of the stored output
+    assert rel_err(out, ref) < (8e-3 if dt == BF16 else 1e-4), (case, name)
+
+
+@pytest.mark.parametrize("dt", [BF16, F32])
+def test_conv_out_shape_vs_oracle(L, dt):
+    """conv_out: 320 -> 4 channels at 64x64, written straight to fp32 NCHW (EPI_NCHW_F32, the narrow-N tile)."""
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(B, 320, 64, 64, generator=g)
+    w = torch.randn(4, 320, 3, 3, generator=g) / 2880 ** 0.5
+    b = torch.randn(4, generator=g)
+    xr, wr = (bf16_round(x), bf16_round(w)) if dt == BF16 else (x, w)
+    ref = F.conv2d(xr, wr, b, padding=1)
+    out = torch.empty(ref.shape, device="cuda")
+    dx, dw, db = dev(x), dev(w), dev(b)
+    assert L.lib().ldmseg_op_conv2d(P(dx), None, P(dw), P(db), B, 320, 0, 64, 64, 4, 3, 1, 0, dt, P(out), None) == 0
+    torch.cuda.synchronize()
+    SEEN[dt].add(L.igemm_last_kernel().split(" ")[0])
+    assert rel_err(out, ref) < (1e-3 if dt == BF16 else 1e-4)
+
+
+@pytest.mark.parametrize("mode,dt", [("bf16", BF16), ("fp32", F32)])
+def test_every_forward_instantiation_is_oracle_tested(L, unet_sd, mode, dt):
+    """Run a batch-8, L = 64 forward (BASELINE configs[1]) with the dispatch log on: every igemm instantiation it
+    launches must be one that a per-layer test above has just compared with the oracle."""
+    from ldmseg_amd.models import UNet
+    u = UNet(unet_sd, in_channels=12, device="cuda:0", compute_dtype=mode)
+    x = torch.randn(B, 12, 64, 64, generator=torch.Generator().manual_seed(1)).cuda()
+    L.igemm_log(True)
+    try:
+        y = u(x, 499).sample
+        torch.cuda.synchronize()
+        used = L.igemm_log_read()
+    finally:
+        L.igemm_log(False)
+    assert torch.isfinite(y).all()
+    assert len(used) >= 4, used
+    missing = used - SEEN[dt]
+    assert not missing, f"forward instantiations without a per-layer oracle test: {sorted(missing)}; tested: {sorted(SEEN[dt])}"

@@ -51,3 +51,35 @@ def test_checkpoint_readers(tmp_path):
     cross = dict(usd, **{"mid_block.attentions.0.transformer_blocks.0.attn2.to_q.weight": torch.zeros(1)})
     with pytest.raises(NotImplementedError):
         checkpoint.unet_state_from(dict(data, unet=cross))
+
+
+def test_color_map_and_encode_seg_vs_reference_golden(golden):
+    """utils.color_map / encode_seg against arrays produced by importing the reference (utils.py:240-258,
+    trainers_ldm_cond.py:324-332)."""
+    import numpy as np
+    from ldmseg_amd.utils import color_map, encode_seg
+    g = golden("colormap.npz")
+    assert np.array_equal(color_map(), g["cmap"]) and color_map().dtype == np.uint8
+    assert np.allclose(color_map(normalized=True), g["cmap_norm"], atol=1e-7)
+    assert np.array_equal(encode_seg(g["ids"]), g["painted"])
+    assert np.array_equal(color_map(8), g["cmap"][:8])
+
+
+def test_scheduler_timesteps_cache_follows_reassignment(sched_kw):
+    """The host copy of `timesteps` (used so that step() needs no D2H sync) must never outlive the tensor it mirrors."""
+    import torch
+    from ldmseg_amd.schedulers import DDIMNoiseScheduler
+    s = DDIMNoiseScheduler(**sched_kw)
+    assert s.timesteps_host()[:3] == [999, 998, 997] and len(s.timesteps) == 1000
+    s.set_timesteps_inference(50)
+    assert s.timesteps_host()[:2] == [999, 979]
+    full = s.timesteps
+    s.timesteps = full[10:]
+    assert s.timesteps_host() == [int(v) for v in full[10:]]
+    assert s._timestep_int(s.timesteps[0]) == int(full[10])
+    s.timesteps = torch.tensor([7, 5, 3])
+    assert s.timesteps_host() == [7, 5, 3]
+    s.move_timesteps_to("cpu")
+    assert s.timesteps_host() == [7, 5, 3]
+    s.set_timesteps_inference(10)
+    assert s.timesteps_host() == [int(v) for v in s.timesteps] == list(range(999, 0, -100))

@@ -235,22 +235,49 @@ def test_convt2_and_bilinear(L, dt):
     assert rel_err(out, ref) < 1e-5
 
 
-@pytest.mark.parametrize("policy", [0, 1, 2, 3])
-def test_igemm_tile_policies_agree(L, policy):
-    """The alternative K-loop structures (8-wave 256-row tiles with a 3-stage LDS ring, 4-stage ring
-    for mid-size grids) are selectable tuning knobs; they must all give the reference result."""
-    B, Ci, H, Co = 8, 128, 64, 160        # M = 32768 rows: enough tiles for every policy to engage
-    g = torch.Generator().manual_seed(policy)
+@pytest.fixture
+def tile_policy(L):
+    """Select an igemm tile policy for one test; the value that was active before (read back from the library, never a
+    literal) is restored by the finalizer even when the test fails."""
+    lib = L.lib()
+    saved = lib.ldmseg_debug_get(1)
+
+    def set_policy(bits):
+        assert lib.ldmseg_debug_set(1, (bits & 31) << 8) == 0
+    yield set_policy
+    lib.ldmseg_debug_set(1, saved)
+    assert lib.ldmseg_debug_get(1) == saved
+
+
+# policy bits: 1 = 256-row 8-wave tiles, 2 = 4-stage ring for mid-size grids (and no loader waves), 4 = lone 64-row
+# 4-stage tiles, 8 = pipelined K loop on the 256-row tiles, 16 = 8-wave 128-row tiles (+ loader waves on long K)
+POLICY_SHAPES = {
+    "big": (8, 128, 64, 320, 3),      # M = 32768, 256 tiles of 256x160
+    "mid_longK": (8, 320, 32, 640, 3),   # M = 8192: one 128-row item per CU, 45 K tiles (loader-wave variant)
+    "mid_shortK": (8, 128, 32, 640, 3),  # same grid, 18 K tiles
+    "small": (8, 128, 16, 1280, 1),      # M = 2048: 256 64-row tiles
+}
+
+
+@pytest.mark.parametrize("shape", sorted(POLICY_SHAPES))
+@pytest.mark.parametrize("policy", [0, 1, 2, 3, 4, 5, 8, 9, 13, 16, 17, 18, 20, 21, 25, 29, 31])
+def test_igemm_tile_policies_agree(L, tile_policy, policy, shape):
+    """Every selectable K-loop structure (tile policy bits) must give the reference result on grids where it engages;
+    the shipped policy is whatever ldmseg_debug_get(-1) reports and is covered here like the rest."""
+    B, Ci, H, Co, k = POLICY_SHAPES[shape]
+    g = torch.Generator().manual_seed(policy * 7 + len(shape))
     x = torch.randn(B, Ci, H, H, generator=g)
-    w = torch.randn(Co, Ci, 3, 3, generator=g) / (Ci * 9) ** 0.5
+    w = torch.randn(Co, Ci, k, k, generator=g) / (Ci * k * k) ** 0.5
     b = torch.randn(Co, generator=g)
-    ref = F.conv2d(bf16_round(x), bf16_round(w), b, padding=1)
+    ref = F.conv2d(bf16_round(x), bf16_round(w), b, padding=k // 2)
     out = torch.empty(ref.shape, device="cuda")
     dx, dw, db = dev(x), dev(w), dev(b)
-    try:
-        assert L.lib().ldmseg_debug_set(1, policy << 8) == 0
-        assert L.lib().ldmseg_op_conv2d(P(dx), None, P(dw), P(db), B, Ci, 0, H, H, Co, 3, 1, 0, BF16, P(out), None) == 0
-        torch.cuda.synchronize()
-    finally:
-        L.lib().ldmseg_debug_set(1, 1 << 8)   # default policy
-    assert rel_err(out, ref) < 1e-3
+    tile_policy(policy)
+    assert L.lib().ldmseg_op_igemm(P(dx), None, P(dw), P(db), None, None, B, Ci, 0, H, H, Co, k, 1, 0, 0, 0, 0, BF16,
+                                   P(out), None) == 0
+    torch.cuda.synchronize()
+    assert rel_err(out, ref) < 8e-3, (policy, shape, L.igemm_last_kernel())
+
+
+def test_shipped_policy_is_active_after_the_policy_tests(L):
+    assert L.lib().ldmseg_debug_get(1) == L.lib().ldmseg_debug_get(-1)
