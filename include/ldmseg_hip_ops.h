@@ -43,6 +43,13 @@ int ldmseg_op_bilinear2x(const float* x, int B, int C, int H, int W, int dtype, 
 int ldmseg_op_igemm(const float* x, const float* x2, const float* w, const float* bias, const float* resid,
                     const float* rowbias, int B, int Ci, int Ci2, int H, int W, int Co, int k, int stride, int up, int geglu,
                     int silu, int splits, int dtype, float* out, void* stream);
+/* Kernel timing for tuning (tools/kbench.py): the same launches repeated `iters` times back to back on `stream` between
+ * two HIP events; *us_per_launch = average microseconds (igemm: including the split-K finish kernel if the plan has one). */
+int ldmseg_bench_igemm(const float* x, const float* x2, const float* w, const float* bias, const float* resid,
+                       const float* rowbias, int B, int Ci, int Ci2, int H, int W, int Co, int k, int stride, int up, int geglu,
+                       int silu, int splits, int dtype, int iters, float* us_per_launch, void* stream);
+int ldmseg_bench_attention(const float* qkv, int B, int N, int C, int heads, int dtype, int iters, float* us_per_launch,
+                           void* stream);
 /* "igemm<dtype,BM,BN,WM,WN,NST,PIPE,LDR> splits=S grid=G": template instantiation and plan of the most recent igemm
  * launch of this process - lets a parity test assert WHICH kernel it just compared with the oracle. */
 int ldmseg_igemm_last_kernel(char* buf, int n);

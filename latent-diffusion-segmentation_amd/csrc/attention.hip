@@ -350,7 +350,7 @@ int g_attn_qf1 = 0;
 template <typename T>
 int dispatch(const void* qkv, void* out, int B, int N, int C, int heads, hipStream_t s) {
   const int d = C / heads;
-  const bool big = N >= 256 && !g_attn_qf1;
+  const bool big = N >= 256 && g_attn_qf1 != 1 && g_attn_qf1 != 3;
   switch (d) {
     case 40: return big ? run<T, 40, 2>(qkv, out, B, N, C, heads, s) : run<T, 40, 1>(qkv, out, B, N, C, heads, s);
     case 80: return big ? run<T, 80, 2>(qkv, out, B, N, C, heads, s) : run<T, 80, 1>(qkv, out, B, N, C, heads, s);
@@ -363,8 +363,16 @@ int dispatch(const void* qkv, void* out, int B, int N, int C, int heads, hipStre
 
 void attention_set_qf1(int v) { g_attn_qf1 = v; }
 
+int launch_attention3(const void* qkv, void* out, int B, int N, int C, int heads, int variant, hipStream_t s);   // attention3.hip
+
 int launch_attention(const void* qkv, void* out, int B, int N, int C, int heads, int dtype, hipStream_t s) {
   if (C % heads != 0 || N <= 0) return -2;
+  // bf16 perf mode, head dims 40 / 80: the LDS-DMA + folded-max kernel of attention3.hip (knob value 2 forces this file's
+  // kernel for A/B measurements; 1 = 16 query rows per wave)
+  if (dtype == DT_BF16 && g_attn_qf1 != 2 && g_attn_qf1 != 3) {      // 0, 1, 4, 5: variants of attention3.hip
+    const int r = launch_attention3(qkv, out, B, N, C, heads, g_attn_qf1, s);
+    if (r != -100) return r;
+  }
   return dtype == DT_BF16 ? dispatch<bf16_t>(qkv, out, B, N, C, heads, s) : dispatch<float>(qkv, out, B, N, C, heads, s);
 }
 

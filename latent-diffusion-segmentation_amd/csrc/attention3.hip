@@ -1,0 +1,368 @@
+// Self-attention for the bf16 perf mode, head dims 40 and 80 (the 64x64 / 32x32 levels of the UNet: N = 4096 / 1024
+// tokens at 512x512, 16384 / 4096 at 1024x1024) - the third generation of the kernel in attention.hip, restructured
+// after measuring what actually bounds it on gfx950 (tools/ubench/valu_trans.hip): not the matrix core and not
+// v_exp_f32 as such (a transcendental costs ~1.7 plain VALU slots), but VALU *issue* - one wave issues a VALU
+// instruction every ~5 cycles, so at 2 waves per SIMD a softmax of ~4.2 VALU slots per score runs at half the MFMA
+// rate.  Hence:
+//   * K and V tiles arrive by LDS-DMA (global_load_lds_dwordx4) as "chunk planes": plane c holds the 16-byte chunk c
+//     (8 head-dim columns) of all 64 keys of the tile, 1 KiB = one wave instruction, lane = key.  No staging
+//     registers, no ds_write pass, no transpose: V^T fragments are read with ds_read_b64_tr_b16 (hardware transpose),
+//     K fragments with ds_read_b128; both are bank-conflict free by construction (K planes 1024 B apart, V planes
+//     1152 B apart).  The kernel fits 128 VGPRs: 4 waves per SIMD instead of 2.
+//   * The running row maximum is folded into the matrix product: head dim D < 32*KG leaves spare contraction columns,
+//     column D of K is a constant plane of ones and column D of Q holds -m (bf16-exact by construction), so the scores
+//     leave the MFMA already relative to m and the per-score subtract disappears.  m is only moved when a row's tile
+//     maximum exceeds it by more than THR (= 2^6 headroom for p, harmless with fp32 accumulation); everything that
+//     was accumulated against the old m is rescaled exactly once at that point.
+//   * Row maxima with v_max3_f32 (two scores per instruction); row sums come out of the PV product through a ones
+//     plane of V (column D of O^T), as in attention.hip.
+// Per score that leaves: 1/2 max3 + 1 exp + 1/2 cvt_pk.  Scores are computed transposed (A = K, B = Q) so a lane owns
+// one query row; P never leaves registers.  Same arithmetic contract as attention.hip (bf16 operands, fp32
+// accumulation, softmax(q k^T d^-1/2) v per head); tests/test_ops_gpu.py::test_attention* cover both.
+#include <type_traits>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace ldmseg {
+namespace {
+
+constexpr int BKV3 = 64;
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+// max of three, written for the compiler (it forms v_max3_f32).  NOT inline asm: the operands are MFMA results, an MFMA
+// write needs wait states before a VALU reads it, and hipcc's hazard recognizer pads those only for instructions it can
+// see - an asm v_max3_f32 here read half-written accumulators now and then (wrong maxima -> overflow -> NaN, run-to-run
+// different).  This file is built with -fno-honor-nans so no canonicalising v_max(x, x) is emitted in front.
+__device__ __forceinline__ float max3f(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+// smallest bf16-representable value >= x (finite x), returned as f32
+__device__ __forceinline__ float bf16_ceil(float x) {
+  const uint32_t u = f32_bits(x);
+  return bits_f32(((u & 0x80000000u) ? u : u + 0xffffu) & 0xffff0000u);
+}
+// LDS-DMA of 64 x 16 B: lane l fetches gsrc(l) + OFF into LDS lds_dst + 16 l.  The instruction's immediate offset is
+// applied to the global AND the LDS address, so M0 carries lds_dst - OFF (callers keep lds_dst >= OFF).
+template <int OFF>
+__device__ __forceinline__ void glds16_off(const void* gsrc, unsigned lds_dst) {
+  asm volatile(
+      "s_mov_b32 m0, %1\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %0, off offset:%2"
+      :
+      : "v"(gsrc), "s"(lds_dst - OFF), "i"(OFF)
+      : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
+}
+
+template <int D> struct A3Cfg {
+  static constexpr int DCH = D / 8;                  // data planes per tile and operand (16-byte chunks per row)
+  static constexpr int KG = (D + 1 + 31) / 32;       // 32-wide k-groups of the QK^T contraction (incl. the -m column)
+  static constexpr int DF = (D + 1 + 15) / 16;       // 16-row fragments of O^T (incl. the row-sum row D)
+  static constexpr int NPL = DCH + 1;                // planes incl. the constant ones plane
+  static constexpr int KPS = 1024, VPS = 1152;       // plane strides (bytes)
+  static constexpr int KBYTES = NPL * KPS, VBYTES = NPL * VPS;
+  static constexpr int STAGE = KBYTES + VBYTES;
+  static constexpr int VSH = (4 - DCH % 4) % 4;      // V planes start at wave VSH's successor... balances the DMA instructions over the 4 waves
+  static constexpr int JMAX = (DCH + 3) / 4;
+  static_assert(D % 8 == 0 && D % 32 != 0, "needs a spare contraction column");
+};
+
+// NST LDS stages; the DMA stream runs NST-1 key tiles ahead of the compute stream
+template <int D, int QF, int WPS, int NST>
+__global__ __launch_bounds__(256, WPS) void attn3_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int N, int C,
+                                                         int heads, float scale_log2e) {
+  using Cfg = A3Cfg<D>;
+  constexpr float THR = 6.0f;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lq = lane & 15, lg = lane >> 4;
+
+  // XCD-aware: all query blocks of one (image, head) share an XCD's L2
+  const int nqb = (N + 64 * QF - 1) / (64 * QF);
+  int wg;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int qb = wg % nqb;
+  const int bh = wg / nqb;
+  const int h = bh % heads, b = bh / heads;
+  const size_t ld = (size_t)3 * C;
+  const bf16_t* qbase = qkv + (size_t)b * N * ld + (size_t)h * D;
+  const unsigned char* kbase = (const unsigned char*)(qbase + C);
+  const size_t ldb = ld * sizeof(bf16_t);
+  const int voff_bytes = C * (int)sizeof(bf16_t);          // V sits C elements after K in a token's row
+
+  // ---- constant planes: chunk DCH of every key is [1, 0, 0, 0, 0, 0, 0, 0] in all stages, for K (the -m column) and V
+  // (the row-sum row); the DMA never touches them
+  for (int i = tid; i < NST * 2 * BKV3; i += 256) {
+    const int st = i / (2 * BKV3), rem = i - st * (2 * BKV3), which = rem / BKV3, key = rem - which * BKV3;
+    unsigned char* p = smem + st * Cfg::STAGE + (which ? Cfg::KBYTES + Cfg::DCH * Cfg::VPS : Cfg::DCH * Cfg::KPS) + key * 16;
+    *(uint4*)p = make_uint4(0x3f80u, 0u, 0u, 0u);
+  }
+
+  // ---- DMA stream: K plane c = wave + 4j, V plane c = ((wave + VSH) & 3) + 4j; lane = key of the tile
+  const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)smem);
+  const int wv = (wave + Cfg::VSH) & 3;
+  int my_cnt = 0;                                           // DMA instructions this wave issues per tile
+#pragma unroll
+  for (int j = 0; j < Cfg::JMAX; ++j) my_cnt += (wave + 4 * j < Cfg::DCH) + (wv + 4 * j < Cfg::DCH);
+  my_cnt = __builtin_amdgcn_readfirstlane(my_cnt);
+  auto issue_tile = [&](int t, int stage) __attribute__((always_inline)) {
+    const int row = min(t * BKV3 + lane, N - 1);           // keys past N are clamped (finite data) and masked below
+    const unsigned char* rp = kbase + (size_t)row * ldb;
+    const unsigned char* kp = rp + wave * 16;
+    const unsigned char* vp = rp + voff_bytes + wv * 16;
+    const unsigned kdst = __builtin_amdgcn_readfirstlane(lds0 + stage * Cfg::STAGE + wave * Cfg::KPS);
+    const unsigned vdst = __builtin_amdgcn_readfirstlane(lds0 + stage * Cfg::STAGE + Cfg::KBYTES + wv * Cfg::VPS);
+    static_for_n<Cfg::JMAX>([&](auto jc) __attribute__((always_inline)) {
+      constexpr int J = decltype(jc)::value;
+      if (wave + 4 * J < Cfg::DCH) glds16_off<J * 64>(kp, kdst + J * 4 * Cfg::KPS);
+      if (wv + 4 * J < Cfg::DCH) glds16_off<J * 64>(vp, vdst + J * 4 * Cfg::VPS);
+    });
+  };
+  // wait until at most `ahead` tiles of this wave's DMA are still in flight (my_cnt in {2,3,5}: wave-uniform)
+  auto wait_tiles_ahead = [&](int ahead) __attribute__((always_inline)) {
+    if (ahead == 0) { wait_vm<0>(); return; }
+    if (my_cnt == 2) wait_vm<2>();
+    else if (my_cnt == 3) wait_vm<3>();
+    else if (my_cnt == 4) wait_vm<4>();
+    else if (my_cnt == 5) wait_vm<5>();
+    else wait_vm<6>();
+  };
+
+  const int ntiles = (N + BKV3 - 1) / BKV3;
+  const int nfull = N / BKV3;                // tiles without masked keys
+  static_for_n<NST - 1>([&](auto jc) __attribute__((always_inline)) {
+    constexpr int J = decltype(jc)::value;
+    if (J < ntiles) issue_tile(J, J);
+  });
+
+  // ---- Q fragments (MFMA B operand): lane (q = lq, g = lg) holds chunk kg*4+g of its row, pre-scaled by d^-1/2 log2 e
+  const int q0 = qb * 64 * QF + wave * 16 * QF;
+  uint4 qf[QF][Cfg::KG];
+#pragma unroll
+  for (int a = 0; a < QF; ++a) {
+    const int q = q0 + a * 16 + lq;
+#pragma unroll
+    for (int kg = 0; kg < Cfg::KG; ++kg) {
+      const int ch = kg * 4 + lg;
+      uint4 raw = (q < N && ch < Cfg::DCH) ? *(const uint4*)((const unsigned char*)(qbase + (size_t)q * ld) + ch * 16)
+                                           : make_uint4(0, 0, 0, 0);
+      float qv[8];
+      Chunk<bf16_t>::unpack(raw, qv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qv[e] *= scale_log2e;
+      qf[a][kg] = Chunk<bf16_t>::pack(qv);
+    }
+  }
+  constexpr int MKG = Cfg::DCH / 4, MLG = Cfg::DCH % 4;      // the (k-group, lane group) that holds column D of Q
+  const bool holds_m = (lg == MLG);
+
+  f32x4 o[QF][Cfg::DF];
+  float mrow[QF];
+#pragma unroll
+  for (int a = 0; a < QF; ++a) {
+    mrow[a] = 0.f;
+#pragma unroll
+    for (int d = 0; d < Cfg::DF; ++d) o[a][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  // per-lane LDS offsets.  K fragment f, k-group kg: plane min(kg*4+lg, DCH), row 16f + lq  (planes past DCH would be
+  // zero columns: the ones plane is read instead and meets zero columns of Q)
+  int koff[Cfg::KG];
+#pragma unroll
+  for (int kg = 0; kg < Cfg::KG; ++kg) koff[kg] = min(kg * 4 + lg, Cfg::DCH) * Cfg::KPS + lq * 16;
+  // V^T fragment df via ds_read_b64_tr_b16: lane i of a 16-lane group points at key row (i >> 2), 8 bytes (i & 1) of
+  // chunk plane 2df + ((i & 3) >> 1); group g covers keys 4g.. of each 16-key block
+  int voff[Cfg::DF];
+#pragma unroll
+  for (int d = 0; d < Cfg::DF; ++d)
+    voff[d] = Cfg::KBYTES + min(2 * d + ((lq & 3) >> 1), Cfg::DCH) * Cfg::VPS + (4 * lg + (lq >> 2)) * 16 + (lq & 1) * 8;
+
+  // tiles in flight beyond tile 0 after the prologue: min(NST - 1, ntiles) - 1
+  wait_tiles_ahead((NST > 2 && ntiles > 1) ? 1 : 0);
+  __syncthreads();
+
+  // One key tile.  STAGE and RAGGED are compile-time: the LDS offsets of every fragment read fold into immediates, and
+  // the -inf masking of keys past N exists only in the instantiation the last, partial tile runs (as a run-time branch
+  // the compiler if-converts it into ~45 VALU instructions on every tile).
+  auto tile = [&](int t, auto stage_c, auto ragged_c) __attribute__((always_inline)) {
+    constexpr int ST = decltype(stage_c)::value;
+    constexpr bool RAGGED = decltype(ragged_c)::value;
+    if (t + NST - 1 < ntiles) issue_tile(t + NST - 1, (ST + NST - 1) % NST);
+    const unsigned char* sb = smem + ST * Cfg::STAGE;
+    // ---- S^T = K Q^T (already relative to the folded row maxima) ----
+    f32x4 s[QF][4];
+#pragma unroll
+    for (int a = 0; a < QF; ++a)
+#pragma unroll
+      for (int f = 0; f < 4; ++f) s[a][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kg = 0; kg < Cfg::KG; ++kg) {
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        const uint4 kf = *(const uint4*)(sb + koff[kg] + f * 256);
+#pragma unroll
+        for (int a = 0; a < QF; ++a) mma_kgroup<bf16_t>(kf, qf[a][kg], s[a][f]);
+      }
+    }
+    // ---- softmax ----
+    if constexpr (RAGGED) {
+#pragma unroll
+      for (int a = 0; a < QF; ++a)
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (t * BKV3 + 16 * f + 4 * lg + r >= N) s[a][f][r] = -INFINITY;
+    }
+    float tmax[QF];
+    bool need_any = (t == 0);
+#pragma unroll
+    for (int a = 0; a < QF; ++a) {
+      float m0 = max3f(s[a][0][0], s[a][0][1], s[a][0][2]);
+      float m1 = max3f(s[a][0][3], s[a][1][0], s[a][1][1]);
+      float m2 = max3f(s[a][1][2], s[a][1][3], s[a][2][0]);
+      float m3 = max3f(s[a][2][1], s[a][2][2], s[a][2][3]);
+      m0 = max3f(m0, s[a][3][0], s[a][3][1]);
+      m1 = max3f(m1, s[a][3][2], s[a][3][3]);
+      m0 = max3f(m0, m1, m2);
+      // the last step before the cross-lane exchange is a compiler-visible VALU op: v_permlane*_swap needs 2 wait states
+      // after a VALU write of its operand and hipcc pads those only for writes it can see (not for inline asm)
+      m0 = fmaxf(m0, m3);
+      m0 = xor32_max(xor16_max(m0));       // the 4 lanes (l, l^16, l^32, l^48) share the query row
+      tmax[a] = m0;
+      need_any |= tmax[a] > THR;
+    }
+    if (__any(need_any)) {
+      // move the reference maximum of the rows that outgrew it (first tile: of every row): everything accumulated
+      // against the old one is rescaled exactly once, this tile's scores are shifted, and column D of Q is rewritten.
+      // `one` is opaque to the optimiser and defined inside this block: every value below depends on it, so none of this
+      // arithmetic can be speculated into the straight-line path (hipcc otherwise turns the whole block into ~50
+      // unconditional VALU instructions per tile - the very work the folded maximum removes).
+      float one;
+      asm volatile("v_mov_b32 %0, 1.0" : "=v"(one));
+#pragma unroll
+      for (int a = 0; a < QF; ++a) {
+        const bool need = (t == 0) | (tmax[a] > THR);
+        const float mnew = need ? bf16_ceil(mrow[a] + tmax[a]) : mrow[a];
+        const float delta = (mnew - mrow[a]) * one;    // exact: both are bf16 values
+        mrow[a] += delta;
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[a][f][r] -= delta;
+        if (t > 0) {                                    // (nothing accumulated yet on the first tile)
+          const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+          for (int d = 0; d < Cfg::DF; ++d) o[a][d] *= alpha;
+        }
+        if (holds_m) qf[a][MKG].x = f32_bits(-mrow[a]) >> 16;     // column D of Q: bf16(-m), columns D+1.. stay zero
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < QF; ++a)
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[a][f][r] = __builtin_amdgcn_exp2f(s[a][f][r]);
+
+    // ---- O^T += V^T P^T : 32-key group hh = score fragments 2hh, 2hh+1 ----
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      uint4 pb[QF];
+#pragma unroll
+      for (int a = 0; a < QF; ++a) {
+        const float p0 = s[a][2 * hh][0], p1 = s[a][2 * hh][1], p2 = s[a][2 * hh][2], p3 = s[a][2 * hh][3];
+        const float p4 = s[a][2 * hh + 1][0], p5 = s[a][2 * hh + 1][1], p6 = s[a][2 * hh + 1][2], p7 = s[a][2 * hh + 1][3];
+        pb[a] = make_uint4(pack_bf16x2(p0, p1), pack_bf16x2(p2, p3), pack_bf16x2(p4, p5), pack_bf16x2(p6, p7));
+      }
+#pragma unroll
+      for (int d = 0; d < Cfg::DF; ++d) {
+        typedef __attribute__((address_space(3))) s16x4* lds_v4;
+        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(sb + voff[d] + (32 * hh) * 16));
+        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(sb + voff[d] + (32 * hh + 16) * 16));
+        const uint2 a0 = __builtin_bit_cast(uint2, v0), a1 = __builtin_bit_cast(uint2, v1);
+        const uint4 vf = make_uint4(a0.x, a0.y, a1.x, a1.y);
+#pragma unroll
+        for (int a = 0; a < QF; ++a) mma_kgroup<bf16_t>(vf, pb[a], o[a][d]);
+      }
+    }
+    // the next tile must have landed before anyone reads it; the one after may stay in flight
+    if (t + 1 < ntiles) wait_tiles_ahead((NST > 2 && t + 2 < ntiles) ? 1 : 0);
+    __syncthreads();
+  };
+  for (int t0 = 0; t0 < ntiles; t0 += NST) {
+    static_for_n<NST>([&](auto sc) __attribute__((always_inline)) {
+      const int t = t0 + decltype(sc)::value;
+      if (t < nfull) tile(t, sc, std::false_type{});
+      else if (t < ntiles) tile(t, sc, std::true_type{});
+    });
+  }
+
+  // ---- normalise and store: lane (q, g) holds d = df*16 + 4g + r; the row sum sits in row D of O^T ----
+#pragma unroll
+  for (int a = 0; a < QF; ++a) {
+    const float l = __shfl(o[a][D / 16][(D % 16) % 4], lq + 16 * ((D % 16) / 4), 64);
+    const float inv = 1.0f / l;
+    const int q = q0 + a * 16 + lq;
+    if (q >= N) continue;
+    bf16_t* op = out + ((size_t)b * N + q) * C + (size_t)h * D;
+#pragma unroll
+    for (int d = 0; d < Cfg::DF; ++d) {
+      const int dd = d * 16 + 4 * lg;
+      if (dd >= D) continue;
+      const f32x4 v = o[a][d] * inv;
+      const float v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3];
+      *(uint2*)(op + dd) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+    }
+  }
+}
+
+template <int D, int QF, int WPS, int NST>
+int run3(const void* qkv, void* out, int B, int N, int C, int heads, hipStream_t s) {
+  using Cfg = A3Cfg<D>;
+  const size_t lds = (size_t)NST * Cfg::STAGE;
+  auto kern = attn3_kernel<D, QF, WPS, NST>;
+  static bool attr_set[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!attr_set[dev]) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set[dev] = true;
+  }
+  const int nqb = (N + 64 * QF - 1) / (64 * QF);
+  const float scale_log2e = (1.0f / sqrtf((float)D)) * 1.4426950408889634f;
+  hipLaunchKernelGGL(kern, dim3(nqb * heads * B), dim3(256), lds, s, (const bf16_t*)qkv, (bf16_t*)out, N, C, heads, scale_log2e);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+}  // namespace
+
+// bf16, head dim 40 or 80; returns -100 when the shape is not handled here (caller falls through to attention.hip)
+int launch_attention3(const void* qkv, void* out, int B, int N, int C, int heads, int variant, hipStream_t s) {
+  const int d = C / heads;
+  // variant: 0 = shipped choice; 1, 4, 5 = alternatives kept for A/B measurements (tools/kbench.py)
+  if (d == 40) {
+    if (variant == 1) return run3<40, 1, 4, 3>(qkv, out, B, N, C, heads, s);
+    if (variant == 4) return run3<40, 2, 3, 2>(qkv, out, B, N, C, heads, s);
+    if (variant == 5) return run3<40, 2, 4, 3>(qkv, out, B, N, C, heads, s);
+    return run3<40, 2, 3, 3>(qkv, out, B, N, C, heads, s);
+  }
+  if (d == 80) {
+    if (variant == 1) return run3<80, 1, 3, 2>(qkv, out, B, N, C, heads, s);
+    if (variant == 4) return run3<80, 2, 3, 2>(qkv, out, B, N, C, heads, s);
+    if (variant == 5) return run3<80, 1, 2, 3>(qkv, out, B, N, C, heads, s);
+    return run3<80, 2, 2, 3>(qkv, out, B, N, C, heads, s);
+  }
+  return -100;
+}
+
+}  // namespace ldmseg

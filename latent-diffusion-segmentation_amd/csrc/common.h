@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace ldmseg {
@@ -74,6 +76,15 @@ template <> struct Chunk<bf16_t> {
                       pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
   }
 };
+
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N-1>{})
+template <int N, typename F>
+__device__ __forceinline__ void static_for_n(F&& f) {
+  if constexpr (N > 0) {
+    static_for_n<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
 
 // ---- cross-lane reductions on the VALU (DPP + v_permlane{16,32}_swap), no LDS round trips ----
 __device__ __forceinline__ void swap16(float x, float& a, float& b) {

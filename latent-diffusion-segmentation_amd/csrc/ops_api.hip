@@ -245,9 +245,9 @@ int ldmseg_op_bilinear2x(const float* x, int B, int C, int H, int W, int dtype, 
 // bias, per-image bias row (time embedding), residual and SiLU, or the GEGLU epilogue.  Boundary tensors are NCHW f32:
 // x [B,Ci,H,W], x2 [B,Ci2,H,W] or NULL, w [Co,Ci+Ci2,k,k], resid [B,Cout,Ho,Wo] or NULL, rowbias [B,Co] or NULL,
 // out [B,Cout,Ho,Wo] with Cout = Co (Co/2 for GEGLU, whose w rows are [value | gate] like ff.net.0.proj).
-int ldmseg_op_igemm(const float* x, const float* x2, const float* w, const float* bias, const float* resid,
-                    const float* rowbias, int B, int Ci, int Ci2, int H, int W, int Co, int k, int stride, int up, int geglu,
-                    int silu, int splits, int dtype, float* out, void* stream) {
+static int op_igemm_impl(const float* x, const float* x2, const float* w, const float* bias, const float* resid,
+                         const float* rowbias, int B, int Ci, int Ci2, int H, int W, int Co, int k, int stride, int up, int geglu,
+                         int silu, int splits, int dtype, float* out, void* stream, int time_iters, float* us_per_launch) {
   hipStream_t s = (hipStream_t)stream;
   Temp t;
   const int a = bke(dtype);
@@ -305,7 +305,59 @@ int ldmseg_op_igemm(const float* x, const float* x2, const float* w, const float
   if (sp > 1) { p.splits = sp; p.partial = (float*)t.get((size_t)sp * p.M * Np * sizeof(float)); }
   const int r = launch_igemm(p, dtype, s);
   if (r) return r;
+  if (time_iters > 0 && us_per_launch) {        // kernel timing (tools/): launches back to back on the stream, HIP events around
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    for (int i = 0; i < 3; ++i) (void)launch_igemm(p, dtype, s);
+    (void)hipEventRecord(e0, s);
+    for (int i = 0; i < time_iters; ++i) (void)launch_igemm(p, dtype, s);
+    (void)hipEventRecord(e1, s);
+    (void)hipEventSynchronize(e1);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    *us_per_launch = 1e3f * ms / time_iters;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  }
+  if (!out) return 0;
   return unpack_nhwc(op, out, B, cout, Ho * Wo, cout, dtype, s);
+}
+
+int ldmseg_op_igemm(const float* x, const float* x2, const float* w, const float* bias, const float* resid,
+                    const float* rowbias, int B, int Ci, int Ci2, int H, int W, int Co, int k, int stride, int up, int geglu,
+                    int silu, int splits, int dtype, float* out, void* stream) {
+  return op_igemm_impl(x, x2, w, bias, resid, rowbias, B, Ci, Ci2, H, W, Co, k, stride, up, geglu, silu, splits, dtype, out,
+                       stream, 0, nullptr);
+}
+// same launch, then `iters` more back to back with HIP events around them: average microseconds per launch (incl. the
+// split-K finish kernel when the plan has one).  Tuning tool (tools/kbench.py), not a product call.
+int ldmseg_bench_igemm(const float* x, const float* x2, const float* w, const float* bias, const float* resid,
+                       const float* rowbias, int B, int Ci, int Ci2, int H, int W, int Co, int k, int stride, int up, int geglu,
+                       int silu, int splits, int dtype, int iters, float* us_per_launch, void* stream) {
+  return op_igemm_impl(x, x2, w, bias, resid, rowbias, B, Ci, Ci2, H, W, Co, k, stride, up, geglu, silu, splits, dtype, nullptr,
+                       stream, iters, us_per_launch);
+}
+int ldmseg_bench_attention(const float* qkv, int B, int N, int C, int heads, int dtype, int iters, float* us_per_launch,
+                           void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  Temp t;
+  void* qp = t.get((size_t)B * N * 3 * C * es(dtype));
+  to_dev_dtype(qkv, qp, (size_t)B * N * 3 * C, dtype, s);
+  void* op = t.get((size_t)B * N * C * es(dtype));
+  for (int i = 0; i < 3; ++i) {
+    const int r = launch_attention(qp, op, B, N, C, heads, dtype, s);
+    if (r) return r;
+  }
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  (void)hipEventRecord(e0, s);
+  for (int i = 0; i < iters; ++i) (void)launch_attention(qp, op, B, N, C, heads, dtype, s);
+  (void)hipEventRecord(e1, s);
+  (void)hipEventSynchronize(e1);
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  *us_per_launch = 1e3f * ms / iters;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return 0;
 }
 
 }  // extern "C"

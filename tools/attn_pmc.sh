@@ -1,0 +1,11 @@
+#!/bin/bash
+# PMC passes over the N=4096 / d=40 attention launch (run on the GPU box from the repo root)
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${1:-attn_pmc}; mkdir -p $O
+cd /tmp; export TMPDIR=/tmp
+CMD="python $R/tools/kbench.py attn 4096 320"
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVES -d $O/p1 -- $CMD > $O/p1.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $O/p2 -- $CMD > $O/p2.log 2>&1
+rocprofv3 --pmc SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL GRBM_GUI_ACTIVE -d $O/p3 -- $CMD > $O/p3.log 2>&1
+for d in p1 p2 p3; do python $R/tools/pmc_query.py $O/$d attn3_kernel > $O/$d.txt 2>&1; python $R/tools/pmc_query.py $O/$d attention_kernel >> $O/$d.txt 2>&1; done
+cat $O/p1.txt $O/p2.txt $O/p3.txt
+find $O -name "*.db" -size +5M -delete

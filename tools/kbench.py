@@ -1,0 +1,70 @@
+#!/usr/bin/env python
+"""Kernel-level timing of the UNet's launch shapes on the MI355X (tuning tool; product code never calls this).
+
+    python tools/kbench.py attn [N C ...]        attention at B=8
+    python tools/kbench.py igemm                 the B=8, L=64 layer shapes (same list as tests/test_igemm_shapes_gpu.py)
+
+Prints microseconds per launch (HIP events around back-to-back launches), achieved TFLOP/s and the instantiation."""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, os.path.join(ROOT, "latent-diffusion-segmentation_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: E402
+from ldmseg_amd import _lib  # noqa: E402
+
+L = _lib.lib()
+P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+DT = {"bf16": 1, "fp32": 0}
+
+
+def attn(B, N, Cc, dt="bf16", iters=20):
+    qkv = torch.randn(B, N, 3 * Cc, device="cuda")
+    us = C.c_float()
+    _lib.check(L.ldmseg_bench_attention(P(qkv), B, N, Cc, 8, DT[dt], iters, C.byref(us), None), "bench_attention")
+    fl = 4.0 * B * 8 * N * N * (Cc / 8)
+    print(f"attention B={B} N={N} C={Cc} {dt}: {us.value:9.1f} us  {fl / us.value / 1e6:7.1f} TF/s")
+    return us.value
+
+
+def igemm(case, dt="bf16", iters=20, B=8):
+    H, Ci, Ci2, Co, k, stride, up, geglu, use_res, use_rb = case
+    ct = Ci + Ci2
+    x = torch.randn(B, Ci, H, H, device="cuda")
+    x2 = torch.randn(B, Ci2, H, H, device="cuda") if Ci2 else None
+    w = torch.randn(Co, ct, k, k, device="cuda") / (ct * k * k) ** 0.5
+    b = torch.randn(Co, device="cuda")
+    Hl = 2 * H if up else H
+    Ho = (Hl - 1) // 2 + 1 if (k == 3 and stride == 2) else Hl
+    cout = Co // 2 if geglu else Co
+    res = torch.randn(B, cout, Ho, Ho, device="cuda") if use_res else None
+    rb = torch.randn(B, Co, device="cuda") if use_rb else None
+    us = C.c_float()
+    _lib.check(L.ldmseg_bench_igemm(P(x), P(x2), P(w), P(b), P(res), P(rb), B, Ci, Ci2, H, H, Co, k, stride, up, geglu, 0, 0,
+                                    DT[dt], iters, C.byref(us), None), "bench_igemm")
+    fl = 2.0 * B * Ho * Ho * Co * ct * k * k
+    name = _lib.igemm_last_kernel()
+    print(f"M={B * Ho * Ho:6d} N={Co:5d} K={ct * k * k:6d} k={k} s={stride} up={up} geglu={geglu} res={use_res} rb={use_rb}: "
+          f"{us.value:8.1f} us {fl / us.value / 1e6:7.1f} TF/s  {name}")
+    return us.value, fl
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "attn"
+    dt = os.environ.get("DT", "bf16")
+    if what == "attn":
+        shapes = [(8, 4096, 320), (8, 1024, 640), (8, 256, 1280), (8, 64, 1280), (4, 16384, 320), (4, 4096, 640)]
+        if len(sys.argv) > 3:
+            shapes = [(int(os.environ.get("B", 8)), int(sys.argv[2]), int(sys.argv[3]))]
+        for s in shapes:
+            attn(*s, dt=dt)
+    else:
+        from test_igemm_shapes_gpu import SHAPES
+        tot_us = tot_fl = 0.0
+        for c in SHAPES:
+            u, f = igemm(c, dt)
+            tot_us += u
+            tot_fl += f
+        print(f"sum over distinct shapes: {tot_us:.1f} us, {tot_fl / tot_us / 1e6:.1f} TF/s")
