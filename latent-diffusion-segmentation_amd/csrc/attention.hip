@@ -369,7 +369,7 @@ int launch_attention(const void* qkv, void* out, int B, int N, int C, int heads,
   if (C % heads != 0 || N <= 0) return -2;
   // bf16 perf mode, head dims 40 / 80: the LDS-DMA + folded-max kernel of attention3.hip (knob value 2 forces this file's
   // kernel for A/B measurements; 1 = 16 query rows per wave)
-  if (dtype == DT_BF16 && g_attn_qf1 != 2 && g_attn_qf1 != 3) {      // 0, 1, 4, 5: variants of attention3.hip
+  if (dtype == DT_BF16 && g_attn_qf1 != 2 && g_attn_qf1 != 3) {      // 0, 1, 4..7: variants of attention3.hip
     const int r = launch_attention3(qkv, out, B, N, C, heads, g_attn_qf1, s);
     if (r != -100) return r;
   }

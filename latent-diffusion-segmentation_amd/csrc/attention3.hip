@@ -71,7 +71,7 @@ template <int D> struct A3Cfg {
 };
 
 // NST LDS stages; the DMA stream runs NST-1 key tiles ahead of the compute stream
-template <int D, int QF, int WPS, int NST>
+template <int D, int QF, int WPS, int NST, bool PIPE>
 __global__ __launch_bounds__(256, WPS) void attn3_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int N, int C,
                                                          int heads, float scale_log2e) {
   using Cfg = A3Cfg<D>;
@@ -186,126 +186,164 @@ __global__ __launch_bounds__(256, WPS) void attn3_kernel(const bf16_t* __restric
   for (int d = 0; d < Cfg::DF; ++d)
     voff[d] = Cfg::KBYTES + min(2 * d + ((lq & 3) >> 1), Cfg::DCH) * Cfg::VPS + (4 * lg + (lq >> 2)) * 16 + (lq & 1) * 8;
 
-  // tiles in flight beyond tile 0 after the prologue: min(NST - 1, ntiles) - 1
-  wait_tiles_ahead((NST > 2 && ntiles > 1) ? 1 : 0);
-  __syncthreads();
-
-  // One key tile.  STAGE and RAGGED are compile-time: the LDS offsets of every fragment read fold into immediates, and
-  // the -inf masking of keys past N exists only in the instantiation the last, partial tile runs (as a run-time branch
-  // the compiler if-converts it into ~45 VALU instructions on every tile).
-  auto tile = [&](int t, auto stage_c, auto ragged_c) __attribute__((always_inline)) {
-    constexpr int ST = decltype(stage_c)::value;
-    constexpr bool RAGGED = decltype(ragged_c)::value;
-    if (t + NST - 1 < ntiles) issue_tile(t + NST - 1, (ST + NST - 1) % NST);
-    const unsigned char* sb = smem + ST * Cfg::STAGE;
-    // ---- S^T = K Q^T (already relative to the folded row maxima) ----
-    f32x4 s[QF][4];
-#pragma unroll
-    for (int a = 0; a < QF; ++a)
-#pragma unroll
-      for (int f = 0; f < 4; ++f) s[a][f] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kg = 0; kg < Cfg::KG; ++kg) {
-#pragma unroll
-      for (int f = 0; f < 4; ++f) {
-        const uint4 kf = *(const uint4*)(sb + koff[kg] + f * 256);
-#pragma unroll
-        for (int a = 0; a < QF; ++a) mma_kgroup<bf16_t>(kf, qf[a][kg], s[a][f]);
-      }
-    }
-    // ---- softmax ----
-    if constexpr (RAGGED) {
-#pragma unroll
-      for (int a = 0; a < QF; ++a)
-#pragma unroll
-        for (int f = 0; f < 4; ++f)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (t * BKV3 + 16 * f + 4 * lg + r >= N) s[a][f][r] = -INFINITY;
-    }
-    float tmax[QF];
-    bool need_any = (t == 0);
-#pragma unroll
-    for (int a = 0; a < QF; ++a) {
-      float m0 = max3f(s[a][0][0], s[a][0][1], s[a][0][2]);
-      float m1 = max3f(s[a][0][3], s[a][1][0], s[a][1][1]);
-      float m2 = max3f(s[a][1][2], s[a][1][3], s[a][2][0]);
-      float m3 = max3f(s[a][2][1], s[a][2][2], s[a][2][3]);
-      m0 = max3f(m0, s[a][3][0], s[a][3][1]);
-      m1 = max3f(m1, s[a][3][2], s[a][3][3]);
-      m0 = max3f(m0, m1, m2);
-      // the last step before the cross-lane exchange is a compiler-visible VALU op: v_permlane*_swap needs 2 wait states
-      // after a VALU write of its operand and hipcc pads those only for writes it can see (not for inline asm)
-      m0 = fmaxf(m0, m3);
-      m0 = xor32_max(xor16_max(m0));       // the 4 lanes (l, l^16, l^32, l^48) share the query row
-      tmax[a] = m0;
-      need_any |= tmax[a] > THR;
-    }
-    if (__any(need_any)) {
-      // move the reference maximum of the rows that outgrew it (first tile: of every row): everything accumulated
-      // against the old one is rescaled exactly once, this tile's scores are shifted, and column D of Q is rewritten.
-      // `one` is opaque to the optimiser and defined inside this block: every value below depends on it, so none of this
-      // arithmetic can be speculated into the straight-line path (hipcc otherwise turns the whole block into ~50
-      // unconditional VALU instructions per tile - the very work the folded maximum removes).
-      float one;
-      asm volatile("v_mov_b32 %0, 1.0" : "=v"(one));
-#pragma unroll
-      for (int a = 0; a < QF; ++a) {
-        const bool need = (t == 0) | (tmax[a] > THR);
-        const float mnew = need ? bf16_ceil(mrow[a] + tmax[a]) : mrow[a];
-        const float delta = (mnew - mrow[a]) * one;    // exact: both are bf16 values
-        mrow[a] += delta;
-#pragma unroll
-        for (int f = 0; f < 4; ++f)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) s[a][f][r] -= delta;
-        if (t > 0) {                                    // (nothing accumulated yet on the first tile)
-          const float alpha = __builtin_amdgcn_exp2f(-delta);
-#pragma unroll
-          for (int d = 0; d < Cfg::DF; ++d) o[a][d] *= alpha;
-        }
-        if (holds_m) qf[a][MKG].x = f32_bits(-mrow[a]) >> 16;     // column D of Q: bf16(-m), columns D+1.. stay zero
-      }
-    }
-#pragma unroll
-    for (int a = 0; a < QF; ++a)
-#pragma unroll
-      for (int f = 0; f < 4; ++f)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) s[a][f][r] = __builtin_amdgcn_exp2f(s[a][f][r]);
-
-    // ---- O^T += V^T P^T : 32-key group hh = score fragments 2hh, 2hh+1 ----
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      uint4 pb[QF];
-#pragma unroll
-      for (int a = 0; a < QF; ++a) {
-        const float p0 = s[a][2 * hh][0], p1 = s[a][2 * hh][1], p2 = s[a][2 * hh][2], p3 = s[a][2 * hh][3];
-        const float p4 = s[a][2 * hh + 1][0], p5 = s[a][2 * hh + 1][1], p6 = s[a][2 * hh + 1][2], p7 = s[a][2 * hh + 1][3];
-        pb[a] = make_uint4(pack_bf16x2(p0, p1), pack_bf16x2(p2, p3), pack_bf16x2(p4, p5), pack_bf16x2(p6, p7));
-      }
-#pragma unroll
-      for (int d = 0; d < Cfg::DF; ++d) {
-        typedef __attribute__((address_space(3))) s16x4* lds_v4;
-        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(sb + voff[d] + (32 * hh) * 16));
-        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(sb + voff[d] + (32 * hh + 16) * 16));
-        const uint2 a0 = __builtin_bit_cast(uint2, v0), a1 = __builtin_bit_cast(uint2, v1);
-        const uint4 vf = make_uint4(a0.x, a0.y, a1.x, a1.y);
-#pragma unroll
-        for (int a = 0; a < QF; ++a) mma_kgroup<bf16_t>(vf, pb[a], o[a][d]);
-      }
-    }
-    // the next tile must have landed before anyone reads it; the one after may stay in flight
-    if (t + 1 < ntiles) wait_tiles_ahead((NST > 2 && t + 2 < ntiles) ? 1 : 0);
-    __syncthreads();
-  };
-  for (int t0 = 0; t0 < ntiles; t0 += NST) {
-    static_for_n<NST>([&](auto sc) __attribute__((always_inline)) {
-      const int t = t0 + decltype(sc)::value;
-      if (t < nfull) tile(t, sc, std::false_type{});
-      else if (t < ntiles) tile(t, sc, std::true_type{});
-    });
+  // ---- the three pieces of a key tile, as macros over a named score array (lambdas taking the arrays by reference made
+  // hipcc index them dynamically -> scratch) ----
+  // S^T = K Q^T for the K planes of LDS stage ST (already relative to the folded row maxima)
+#define A3_QK(SARR, ST)                                                                                         \
+  {                                                                                                             \
+    const unsigned char* kb_ = smem + (ST) * Cfg::STAGE;                                                        \
+    _Pragma("unroll") for (int a = 0; a < QF; ++a)                                                              \
+      _Pragma("unroll") for (int f = 0; f < 4; ++f) SARR[a][f] = f32x4{0.f, 0.f, 0.f, 0.f};                      \
+    _Pragma("unroll") for (int kg = 0; kg < Cfg::KG; ++kg) {                                                    \
+      _Pragma("unroll") for (int f = 0; f < 4; ++f) {                                                           \
+        const uint4 kf = *(const uint4*)(kb_ + koff[kg] + f * 256);                                             \
+        _Pragma("unroll") for (int a = 0; a < QF; ++a) mma_kgroup<bf16_t>(kf, qf[a][kg], SARR[a][f]);           \
+      }                                                                                                         \
+    }                                                                                                           \
   }
+  // softmax numerators of tile T_ in place (SARR <- p), moving the folded maxima when a row outgrew them.  SNXT: scores of
+  // the NEXT tile that were already computed against the old maxima (pipelined loop) and must move with them, or SARR.
+#define A3_SOFTMAX(SARR, SNXT, HAS_NXT, T_, RAGGED_)                                                            \
+  {                                                                                                             \
+    if constexpr (RAGGED_) {                                                                                    \
+      _Pragma("unroll") for (int a = 0; a < QF; ++a)                                                            \
+        _Pragma("unroll") for (int f = 0; f < 4; ++f)                                                           \
+          _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                         \
+            if ((T_) * BKV3 + 16 * f + 4 * lg + r >= N) SARR[a][f][r] = -INFINITY;                              \
+    }                                                                                                           \
+    float tmax[QF];                                                                                             \
+    bool need_any = ((T_) == 0);                                                                                \
+    _Pragma("unroll") for (int a = 0; a < QF; ++a) {                                                            \
+      float m0 = max3f(SARR[a][0][0], SARR[a][0][1], SARR[a][0][2]);                                            \
+      float m1 = max3f(SARR[a][0][3], SARR[a][1][0], SARR[a][1][1]);                                            \
+      float m2 = max3f(SARR[a][1][2], SARR[a][1][3], SARR[a][2][0]);                                            \
+      float m3 = max3f(SARR[a][2][1], SARR[a][2][2], SARR[a][2][3]);                                            \
+      m0 = max3f(m0, SARR[a][3][0], SARR[a][3][1]);                                                             \
+      m1 = max3f(m1, SARR[a][3][2], SARR[a][3][3]);                                                             \
+      m0 = max3f(m0, m1, m2);                                                                                   \
+      m0 = fmaxf(m0, m3);                                                                                       \
+      m0 = xor32_max(xor16_max(m0)); /* the 4 lanes (l, l^16, l^32, l^48) share the query row */                \
+      tmax[a] = m0;                                                                                             \
+      need_any |= tmax[a] > THR;                                                                                \
+    }                                                                                                           \
+    if (__any(need_any)) {                                                                                      \
+      /* Move the reference maximum of the rows that outgrew it (first tile: of every row): everything */       \
+      /* accumulated against the old one is rescaled exactly once, the scores in flight are shifted and */      \
+      /* column D of Q is rewritten.  `one` is opaque to the optimiser and defined inside this block: every */  \
+      /* value below depends on it, so none of this arithmetic can be speculated into the straight-line */      \
+      /* path (hipcc otherwise turns the block into ~50 unconditional VALU instructions per tile). */           \
+      float one;                                                                                                \
+      asm volatile("v_mov_b32 %0, 1.0" : "=v"(one));                                                            \
+      _Pragma("unroll") for (int a = 0; a < QF; ++a) {                                                          \
+        const bool need = ((T_) == 0) | (tmax[a] > THR);                                                        \
+        const float mnew = need ? bf16_ceil(mrow[a] + tmax[a]) : mrow[a];                                       \
+        const float delta = (mnew - mrow[a]) * one; /* exact: both are bf16 values */                           \
+        mrow[a] += delta;                                                                                       \
+        _Pragma("unroll") for (int f = 0; f < 4; ++f)                                                           \
+          _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                       \
+            SARR[a][f][r] -= delta;                                                                             \
+            if (HAS_NXT) SNXT[a][f][r] -= delta;                                                                \
+          }                                                                                                     \
+        if ((T_) > 0) { /* (nothing accumulated yet on the first tile) */                                       \
+          const float alpha = __builtin_amdgcn_exp2f(-delta);                                                   \
+          _Pragma("unroll") for (int d = 0; d < Cfg::DF; ++d) o[a][d] *= alpha;                                 \
+        }                                                                                                       \
+        if (holds_m) qf[a][MKG].x = f32_bits(-mrow[a]) >> 16; /* column D of Q: bf16(-m); D+1.. stay zero */    \
+      }                                                                                                         \
+    }                                                                                                           \
+    _Pragma("unroll") for (int a = 0; a < QF; ++a)                                                              \
+      _Pragma("unroll") for (int f = 0; f < 4; ++f)                                                             \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) SARR[a][f][r] = __builtin_amdgcn_exp2f(SARR[a][f][r]);    \
+  }
+  // O^T += V^T P^T with the V planes of stage ST; 32-key group hh = score fragments 2hh, 2hh+1
+#define A3_PV(SARR, ST)                                                                                         \
+  {                                                                                                             \
+    const unsigned char* vb_ = smem + (ST) * Cfg::STAGE;                                                        \
+    _Pragma("unroll") for (int hh = 0; hh < 2; ++hh) {                                                          \
+      uint4 pb[QF];                                                                                             \
+      _Pragma("unroll") for (int a = 0; a < QF; ++a) {                                                          \
+        const float p0 = SARR[a][2 * hh][0], p1 = SARR[a][2 * hh][1], p2 = SARR[a][2 * hh][2], p3 = SARR[a][2 * hh][3]; \
+        const float p4 = SARR[a][2 * hh + 1][0], p5 = SARR[a][2 * hh + 1][1], p6 = SARR[a][2 * hh + 1][2],     \
+                    p7 = SARR[a][2 * hh + 1][3];                                                                \
+        pb[a] = make_uint4(pack_bf16x2(p0, p1), pack_bf16x2(p2, p3), pack_bf16x2(p4, p5), pack_bf16x2(p6, p7)); \
+      }                                                                                                         \
+      _Pragma("unroll") for (int d = 0; d < Cfg::DF; ++d) {                                                     \
+        typedef __attribute__((address_space(3))) s16x4* lds_v4;                                                \
+        const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(vb_ + voff[d] + (32 * hh) * 16));      \
+        const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(vb_ + voff[d] + (32 * hh + 16) * 16)); \
+        const uint2 a0 = __builtin_bit_cast(uint2, v0), a1 = __builtin_bit_cast(uint2, v1);                     \
+        const uint4 vf = make_uint4(a0.x, a0.y, a1.x, a1.y);                                                    \
+        _Pragma("unroll") for (int a = 0; a < QF; ++a) mma_kgroup<bf16_t>(vf, pb[a], o[a][d]);                  \
+      }                                                                                                         \
+    }                                                                                                           \
+  }
+
+  f32x4 sA[QF][4];
+  if constexpr (!PIPE) {
+    // tiles in flight beyond tile 0 after the prologue: min(NST - 1, ntiles) - 1
+    wait_tiles_ahead((NST > 2 && ntiles > 1) ? 1 : 0);
+    __syncthreads();
+    // One key tile.  STAGE and RAGGED are compile-time: the LDS offsets of every fragment read fold into immediates,
+    // and the -inf masking of keys past N exists only in the instantiation the last, partial tile runs (as a run-time
+    // branch the compiler if-converts it into ~45 VALU instructions on every tile).
+    auto tile = [&](int t, auto stage_c, auto ragged_c) __attribute__((always_inline)) {
+      constexpr int ST = decltype(stage_c)::value;
+      constexpr bool RAGGED = decltype(ragged_c)::value;
+      if (t + NST - 1 < ntiles) issue_tile(t + NST - 1, (ST + NST - 1) % NST);
+      A3_QK(sA, ST)
+      A3_SOFTMAX(sA, sA, false, t, RAGGED)
+      A3_PV(sA, ST)
+      // the next tile must have landed before anyone reads it; the one after may stay in flight
+      if (t + 1 < ntiles) wait_tiles_ahead((NST > 2 && t + 2 < ntiles) ? 1 : 0);
+      __syncthreads();
+    };
+    for (int t0 = 0; t0 < ntiles; t0 += NST) {
+      static_for_n<NST>([&](auto sc) __attribute__((always_inline)) {
+        const int t = t0 + decltype(sc)::value;
+        if (t < nfull) tile(t, sc, std::false_type{});
+        else if (t < ntiles) tile(t, sc, std::true_type{});
+      });
+    }
+  } else {
+    // Software-pipelined loop: iteration t issues the QK^T matrix products of tile t+1 BEFORE the softmax of tile t, so
+    // that every wave always has independent MFMA work (QK^T of t+1, then PV of t) next to its VALU work (softmax of t).
+    // In the plain loop a wave alternates between a pure-MFMA and a pure-VALU phase and the SIMD's two pipes only
+    // overlap across waves (measured: MFMA pipe 41 % busy, VALU 22 %, 38 % of the cycles neither).  K therefore runs
+    // two tiles ahead of the compute stream: NST = 4 stages, the DMA stream three tiles ahead.
+    static_assert(!PIPE || NST == 4, "the pipelined loop alternates two score arrays over a 4-stage ring");
+    f32x4 sB[QF][4];
+    wait_tiles_ahead(ntiles > 2 ? 1 : 0);       // tiles 0 and 1 landed (tile 2 may be in flight)
+    __syncthreads();
+    A3_QK(sA, 0)
+#define A3_PIPE_TILE(T_, ST, CUR, NXT, RAGGED_)                                                                 \
+  {                                                                                                             \
+    if ((T_) + 3 < ntiles) issue_tile((T_) + 3, ((ST) + 3) % 4);                                                \
+    const bool has_nxt = (T_) + 1 < ntiles;                                                                     \
+    if (has_nxt) A3_QK(NXT, ((ST) + 1) % 4)                                                                     \
+    A3_SOFTMAX(CUR, NXT, has_nxt, T_, RAGGED_)                                                                  \
+    A3_PV(CUR, ST)                                                                                              \
+    /* tile T_+2 (its K planes feed the next iteration) must have landed; T_+3 may stay in flight */            \
+    if ((T_) + 2 < ntiles) wait_tiles_ahead((T_) + 3 < ntiles ? 1 : 0);                                         \
+    __syncthreads();                                                                                            \
+  }
+#define A3_PIPE_STEP(T_, ST, CUR, NXT)                                     \
+  {                                                                        \
+    const int t_ = (T_);                                                   \
+    if (t_ < nfull) A3_PIPE_TILE(t_, ST, CUR, NXT, false)                  \
+    else if (t_ < ntiles) A3_PIPE_TILE(t_, ST, CUR, NXT, true)             \
+  }
+    for (int t0 = 0; t0 < ntiles; t0 += 4) {      // no lambdas here: the score arrays must stay in registers
+      A3_PIPE_STEP(t0 + 0, 0, sA, sB)
+      A3_PIPE_STEP(t0 + 1, 1, sB, sA)
+      A3_PIPE_STEP(t0 + 2, 2, sA, sB)
+      A3_PIPE_STEP(t0 + 3, 3, sB, sA)
+    }
+#undef A3_PIPE_STEP
+#undef A3_PIPE_TILE
+  }
+#undef A3_QK
+#undef A3_SOFTMAX
+#undef A3_PV
 
   // ---- normalise and store: lane (q, g) holds d = df*16 + 4g + r; the row sum sits in row D of O^T ----
 #pragma unroll
@@ -326,11 +364,11 @@ __global__ __launch_bounds__(256, WPS) void attn3_kernel(const bf16_t* __restric
   }
 }
 
-template <int D, int QF, int WPS, int NST>
+template <int D, int QF, int WPS, int NST, bool PIPE = false>
 int run3(const void* qkv, void* out, int B, int N, int C, int heads, hipStream_t s) {
   using Cfg = A3Cfg<D>;
   const size_t lds = (size_t)NST * Cfg::STAGE;
-  auto kern = attn3_kernel<D, QF, WPS, NST>;
+  auto kern = attn3_kernel<D, QF, WPS, NST, PIPE>;
   static bool attr_set[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
@@ -354,6 +392,7 @@ int launch_attention3(const void* qkv, void* out, int B, int N, int C, int heads
     if (variant == 1) return run3<40, 1, 4, 3>(qkv, out, B, N, C, heads, s);
     if (variant == 4) return run3<40, 2, 3, 2>(qkv, out, B, N, C, heads, s);
     if (variant == 5) return run3<40, 2, 4, 3>(qkv, out, B, N, C, heads, s);
+    if (variant == 7) return run3<40, 2, 2, 4, true>(qkv, out, B, N, C, heads, s);   // software-pipelined loop: 248 VGPRs, measured 11 % slower
     return run3<40, 2, 3, 3>(qkv, out, B, N, C, heads, s);
   }
   if (d == 80) {

@@ -220,10 +220,10 @@ def attn_variant(L):
     lib.ldmseg_debug_set(2, 0)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 7])
 @pytest.mark.parametrize("B,N,Cc", [(2, 1024, 320), (1, 200, 640), (1, 4096, 320)])
 def test_attention_variants(L, attn_variant, variant, B, N, Cc):
-    """Every selectable bf16 attention kernel (attention3.hip variants 0/1/4/5, attention.hip 2/3) vs the fp64 reference."""
+    """Every selectable bf16 attention kernel (attention3.hip variants 0/1/4/5/7, attention.hip 2/3) vs the fp64 reference."""
     g = torch.Generator().manual_seed(N + Cc + variant)
     qkv = torch.randn(B, N, 3 * Cc, generator=g)
     qkv[:, :, :Cc] *= 2.0
