@@ -114,7 +114,7 @@ constexpr bool epi_stage_dedicated() { return epi_stage_bytes<BM, BN, WAVES_M, W
 // computes the current tile, waits with a COUNTED vmcnt until the next tile has landed (later ones
 // stay in flight) and passes the single barrier.
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int NST, bool PIPE, int LDR>
-__global__ __launch_bounds__((WAVES_M * WAVES_N + LDR) * 64, 2) void igemm_kernel(const IgemmParams p) {   // <=256 regs: 2 waves/SIMD
+__global__ __launch_bounds__((WAVES_M * WAVES_N + LDR) * 64, (WAVES_M * WAVES_N + LDR) > 8 ? 3 : 2) void igemm_kernel(const IgemmParams p) {   // <=256 regs at 2 waves/SIMD; 12-wave workgroups (8 compute + 4 loader waves) need 3 per SIMD: <=168
   constexpr int NW = WAVES_M * WAVES_N;   // 4 waves (128-row tiles, 2 workgroups/CU) or 8 (256-row tiles)
   static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
   // LDR > 0: producer / consumer split.  Waves NW..NW+LDR-1 only run the LDS-DMA stream (they sit blocked in the
@@ -775,7 +775,7 @@ const void* zero_page() {
   return z[dev];
 }
 
-constexpr int kDefaultPolicy = 29;
+constexpr int kDefaultPolicy = 61;
 }  // namespace
 std::string igemm_dispatch_name(const IgemmDispatch& d);
 namespace {
@@ -786,6 +786,8 @@ int g_dbg = 0;       // ablation flags (profiling experiments only)
 void* g_tsbuf = nullptr;   // s_memtime stamp buffer (LDMSEG_IGEMM_ABLATE builds)
 int g_big = kDefaultPolicy;      // bit0: 8-wave 256-row tiles with a 3-stage ring (-0.15 ms per forward, on);
                      // bit1: 4-stage ring, one workgroup per CU, for mid-size grids (+0.5 ms, off)
+                     // bit2: lone 64-row 4-stage tiles; bit3: pipelined K loop on the 256-row tiles; bit4: 8-wave 128-row
+                     // tiles (+ loader waves on long K); bit5: loader waves on the 256-row tiles (long K / GEGLU)
 
 template <typename T, int BM, int BN, int WM, int WN, int NST = 2, bool PIPE = false, int LDR = 0>
 int run(const IgemmParams& pin, hipStream_t s) {
@@ -853,14 +855,22 @@ int dispatch(const IgemmParams& p, hipStream_t s) {
   if (mid8 && !(g_big & 2) && (p.taps * (p.C0 + p.C1) / (int)(kRowBytes / sizeof(T))) / (p.splits > 1 ? p.splits : 1) >= 40)
     return bn == 160 ? run<T, 128, 160, 2, 2, 4, true, 4>(p, s) : run<T, 128, 128, 2, 2, 4, true, 4>(p, s);
   if (mid8) return bn == 160 ? run<T, 128, 160, 4, 2, 3, true>(p, s) : run<T, 128, 128, 4, 2, 3, true>(p, s);
+  // 256-row tiles with four extra loader waves (12-wave workgroups): issuing an LDS-DMA instruction parks the issuing wave
+  // for 60-185 cycles (MI355X_MICROARCH.md), which in the 8-wave form comes straight out of the MFMA stream.  Measured on the
+  // B = 8, L = 64 layer shapes (tools/kbench.py): 3x3 convs with K >= 2880 5-17 % faster, GEGLU 5-10 %, K <= 960 GEMMs 5-13 %
+  // slower (prologue / epilogue bound: the loader waves only add barrier participants) -> long K slices and GEGLU only.
+  const int nk_slice = (p.taps * (p.C0 + p.C1) / (int)(kRowBytes / sizeof(T))) / (p.splits > 1 ? p.splits : 1);
+  const bool ldr_big = (g_big & 32) && sizeof(T) == 2 && (nk_slice >= 24 || p.epi == EPI_GEGLU);   // (the fp32 instantiation spills)
   const long t64 = (long)((p.M + 63) / 64) * (p.N / bn) * (p.splits > 1 ? p.splits : 1);
   const bool lone = (g_big & 4) && small && !big && !deep && t64 <= num_cus();
   switch (bn) {
     case 160:
+      if (big && ldr_big) return run<T, 256, 160, 4, 2, 3, true, 4>(p, s);
       return big ? ((g_big & 8) ? run<T, 256, 160, 4, 2, 3, true>(p, s) : run<T, 256, 160, 4, 2, 3, false>(p, s)) : deep ? run<T, 128, 160, 2, 2, 4>(p, s)
                  : lone ? run<T, 64, 160, 2, 2, 4>(p, s)
                  : small ? run<T, 64, 160, 2, 2>(p, s) : run<T, 128, 160, 2, 2>(p, s);
     case 128:
+      if (big && ldr_big) return run<T, 256, 128, 4, 2, 3, true, 4>(p, s);
       return big ? ((g_big & 8) ? run<T, 256, 128, 4, 2, 3, true>(p, s) : run<T, 256, 128, 4, 2, 3, false>(p, s)) : deep ? run<T, 128, 128, 2, 2, 4>(p, s)
                  : lone ? run<T, 64, 128, 2, 2, 4>(p, s)
                  : small ? run<T, 64, 128, 2, 2>(p, s) : run<T, 128, 128, 2, 2>(p, s);
@@ -872,7 +882,7 @@ int dispatch(const IgemmParams& p, hipStream_t s) {
 }  // namespace
 
 void igemm_set_tsbuf(void* b) { g_tsbuf = b; }
-void igemm_set_dbg(int f) { g_dbg = f & 0xff; g_big = (f >> 8) & 31; }   // bits 8-12 select the tile policy
+void igemm_set_dbg(int f) { g_dbg = f & 0xff; g_big = (f >> 8) & 63; }   // bits 8-13 select the tile policy
 int igemm_get_dbg() { return (g_big << 8) | g_dbg; }
 int igemm_default_dbg() { return kDefaultPolicy << 8; }
 IgemmDispatch igemm_last_dispatch() { return g_last; }

@@ -259,6 +259,81 @@ class TrainerDiffusion(object):
             return results, {"labels": labels, "counts": counts, "mask_counts": mcounts, "keep": keep}
         return results
 
+    # ------------------------------------------------------------------ evaluation loop body (compute_pq)
+    @staticmethod
+    def crop_padding(prediction: torch.Tensor, padding_mask: torch.Tensor) -> torch.Tensor:
+        """:1172-1178 - bounding box of the non-padded region."""
+        co = padding_mask.nonzero()
+        y0, y1 = int(co[:, 0].min()), int(co[:, 0].max())
+        x0, x1 = int(co[:, 1].min()), int(co[:, 1].max())
+        return prediction[:, y0:y1 + 1, x0:x1 + 1]
+
+    @torch.no_grad()
+    def predict_panoptic(self, rgb_images: torch.Tensor, im_sizes, padding_masks: Optional[torch.Tensor] = None,
+                         num_inference_steps: int = 50, guidance_scale: float = 7.5, seed: Optional[int] = None,
+                         threshold_output: bool = True, threshold_mode: str = "max", scheduler=None, rgb_size: Optional[int] = None,
+                         mask_th: float = 0.5, count_th: int = 512, overlap_th: float = 0.5, ignore_label: int = 0,
+                         return_intermediates: bool = False):
+        """One batch of `compute_pq` (:1218-1313): RGB images [B,3,S,S] in [0,1] on the GPU -> `processed_results`
+        (per image {"panoptic_seg": (panoptic map at the original size (h, w), segments_info)}).
+        Pixels -> image-VAE latents -> DDIM sampling -> seg-VAE logits -> bilinear to the input size -> crop the padding
+        -> bilinear to (h, w) -> argmax / thresholds / segment filtering on the GPU (ldmseg_panoptic_postprocess)."""
+        import torch.nn.functional as F
+        if self.vae_image is None:
+            raise ValueError("predict_panoptic needs the image VAE (TrainerDiffusion(..., vae_image=...))")
+        rgb_images = _lib.require_cuda_f32(rgb_images, "rgb_images")
+        B = rgb_images.shape[0]
+        if scheduler is None:
+            scheduler = self.noise_scheduler
+            scheduler.set_timesteps_inference(num_inference_steps)
+        rgb_latents, _ = self.encode_inputs(rgb_images, encode_func=self.vae_image.encode,
+                                            scaling_factor=self.vae_image.scaling_factor, resize=rgb_size)
+        latents = self.sample([""] * B, num_inference_steps, guidance_scale, seed, rgb_latents=rgb_latents,
+                              scheduler=scheduler, disable_progress_bar=True)
+        logits = self.decode_latents(latents, return_logits=True)
+        logits = F.interpolate(logits, size=(rgb_images.shape[-2], rgb_images.shape[-1]), mode="bilinear",
+                               align_corners=False)                                           # :1252-1257
+        results = []
+        for i in range(B):
+            m = logits[i]
+            if padding_masks is not None:
+                m = self.crop_padding(m, padding_masks[i])                                    # :1263
+            h, w = int(im_sizes[i][0]), int(im_sizes[i][1])
+            m = F.interpolate(m[None].float(), size=(h, w), mode="bilinear", align_corners=False)   # :1266-1271
+            results += self.postprocess_panoptic(m.contiguous(), threshold_output=threshold_output,
+                                                 threshold_mode=threshold_mode, mask_th=mask_th, count_th=count_th,
+                                                 overlap_th=overlap_th, ignore_label=ignore_label)
+        if return_intermediates:
+            return results, {"rgb_latents": rgb_latents, "latents": latents, "logits": logits}
+        return results
+
+    @torch.no_grad()
+    def compute_pq(self, dataloader, evaluator, num_inference_steps: int = 50, guidance_scale: float = 7.5,
+                   seed: Optional[int] = None, threshold_output: bool = True, max_iter: Optional[int] = None,
+                   threshold_mode: str = "max", **post_kw):
+        """`compute_pq` (:1181-1346) over an iterable of batches shaped like the reference's `collate_fn` output:
+        {'image': [B,3,S,S] in [0,1], 'mask': [B,S,S] padding masks or None, 'meta': [{'image_file', 'image_id',
+        'im_size': (h, w)}, ...]}.  `evaluator` is a PanopticEvaluatorAgnostic; all ranks must call this (the
+        evaluator gathers).  Returns evaluator.evaluate() (rank 0) / None."""
+        evaluator.reset()
+        scheduler = self.noise_scheduler
+        scheduler.set_timesteps_inference(num_inference_steps=num_inference_steps)
+        scheduler.move_timesteps_to(self.device)                                              # :1211-1212
+        for batch_idx, data in enumerate(dataloader):
+            meta = data["meta"]
+            file_names = [x["image_file"] for x in meta]
+            image_ids = [x["image_id"] for x in meta]
+            sizes = [x["im_size"] for x in meta]
+            rgb = data["image"].to(self.device, non_blocking=True)
+            masks = data.get("mask")
+            masks = masks.to(self.device) if masks is not None else None
+            processed = self.predict_panoptic(rgb, sizes, masks, num_inference_steps, guidance_scale, seed,
+                                              threshold_output, threshold_mode, scheduler=scheduler, **post_kw)
+            evaluator.process(file_names, image_ids, processed)
+            if max_iter is not None and batch_idx > max_iter:                                 # (sic, :1332)
+                break
+        return evaluator.evaluate()
+
     @torch.no_grad()
     def encode_inputs(self, images: torch.Tensor, sample_posterior: bool = False, encode_func=None,
                       scaling_factor: Optional[float] = None, resize: Optional[int] = None, weight_dtype=None,

@@ -83,3 +83,21 @@ def test_scheduler_timesteps_cache_follows_reassignment(sched_kw):
     assert s.timesteps_host() == [7, 5, 3]
     s.set_timesteps_inference(10)
     assert s.timesteps_host() == [int(v) for v in s.timesteps] == list(range(999, 0, -100))
+
+
+def test_val_transforms_match_pil(tmp_path):
+    """data.transforms: CropResize(crop_mode=None) is a plain PIL resize (bicubic for images) and ToTensor scales to [0, 1]."""
+    from PIL import Image
+    from ldmseg_amd.data import transforms as T
+    g = np.random.RandomState(1)
+    arr = g.randint(0, 256, size=(37, 53, 3)).astype(np.uint8)
+    p = tmp_path / "im.png"
+    Image.fromarray(arr).save(p)
+    t, (h, w) = T.load_rgb(str(p), 64)
+    assert (h, w) == (37, 53) and t.shape == (3, 64, 64) and t.dtype == torch.float32
+    R = getattr(Image, "Resampling", Image)
+    ref = np.asarray(Image.fromarray(arr).resize((64, 64), resample=R.BICUBIC, reducing_gap=None), dtype=np.float32) / 255
+    assert np.array_equal(t.permute(1, 2, 0).numpy(), ref)
+    ids = Image.fromarray(g.randint(0, 200, size=(10, 12)).astype(np.uint8))
+    small = T.ids_to_tensor(T.crop_resize(ids, (5, 6), "nearest"))
+    assert small.dtype == torch.int64 and small.shape == (5, 6)

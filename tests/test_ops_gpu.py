@@ -323,16 +323,18 @@ def tile_policy(L):
     saved = lib.ldmseg_debug_get(1)
 
     def set_policy(bits):
-        assert lib.ldmseg_debug_set(1, (bits & 31) << 8) == 0
+        assert lib.ldmseg_debug_set(1, (bits & 63) << 8) == 0
     yield set_policy
     lib.ldmseg_debug_set(1, saved)
     assert lib.ldmseg_debug_get(1) == saved
 
 
 # policy bits: 1 = 256-row 8-wave tiles, 2 = 4-stage ring for mid-size grids (and no loader waves), 4 = lone 64-row
-# 4-stage tiles, 8 = pipelined K loop on the 256-row tiles, 16 = 8-wave 128-row tiles (+ loader waves on long K)
+# 4-stage tiles, 8 = pipelined K loop on the 256-row tiles, 16 = 8-wave 128-row tiles (+ loader waves on long K),
+# 32 = loader waves on the 256-row tiles (long K slices / GEGLU)
 POLICY_SHAPES = {
-    "big": (8, 128, 64, 320, 3),      # M = 32768, 256 tiles of 256x160
+    "big": (8, 128, 64, 320, 3),      # M = 32768, 256 tiles of 256x160, 18 K tiles
+    "big_longK": (8, 320, 64, 320, 3),   # same grid, 45 K tiles (12-wave tile with loader waves under bit 32)
     "mid_longK": (8, 320, 32, 640, 3),   # M = 8192: one 128-row item per CU, 45 K tiles (loader-wave variant)
     "mid_shortK": (8, 128, 32, 640, 3),  # same grid, 18 K tiles
     "small": (8, 128, 16, 1280, 1),      # M = 2048: 256 64-row tiles
@@ -340,7 +342,7 @@ POLICY_SHAPES = {
 
 
 @pytest.mark.parametrize("shape", sorted(POLICY_SHAPES))
-@pytest.mark.parametrize("policy", [0, 1, 2, 3, 4, 5, 8, 9, 13, 16, 17, 18, 20, 21, 25, 29, 31])
+@pytest.mark.parametrize("policy", [0, 1, 2, 3, 4, 5, 8, 9, 13, 16, 17, 18, 20, 21, 25, 29, 31, 33, 41, 61, 63])
 def test_igemm_tile_policies_agree(L, tile_policy, policy, shape):
     """Every selectable K-loop structure (tile policy bits) must give the reference result on grids where it engages;
     the shipped policy is whatever ldmseg_debug_get(-1) reports and is covered here like the rest."""

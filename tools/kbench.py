@@ -61,6 +61,8 @@ if __name__ == "__main__":
         for s in shapes:
             attn(*s, dt=dt)
     else:
+        if os.environ.get("POLICY"):
+            L.ldmseg_debug_set(1, int(os.environ["POLICY"]) << 8)
         from test_igemm_shapes_gpu import SHAPES
         tot_us = tot_fl = 0.0
         for c in SHAPES:
