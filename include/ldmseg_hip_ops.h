@@ -43,6 +43,11 @@ int ldmseg_op_bilinear2x(const float* x, int B, int C, int H, int W, int dtype, 
 int ldmseg_op_igemm(const float* x, const float* x2, const float* w, const float* bias, const float* resid,
                     const float* rowbias, int B, int Ci, int Ci2, int H, int W, int Co, int k, int stride, int up, int geglu,
                     int silu, int splits, int dtype, float* out, void* stream);
+/* F.linear(F.layer_norm(x, (K,), gamma, beta, eps), w, bias) - GEGLU on top when geglu=1 - the way the engine runs
+ * norm1 -> to_q|k|v and norm3 -> ff.net.0.proj (diffusers BasicTransformerBlock): one statistics pass over x, then the GEMM on
+ * the un-normalised x with gamma folded into the weights and rstd*(acc - mean*c1) + c2 in the epilogue. */
+int ldmseg_op_ln_linear(const float* x, const float* gamma, const float* beta, const float* w, const float* bias, int M, int K,
+                        int N, float eps, int geglu, int dtype, float* out, void* stream);
 /* Kernel timing for tuning (tools/kbench.py): the same launches repeated `iters` times back to back on `stream` between
  * two HIP events; *us_per_launch = average microseconds (igemm: including the split-K finish kernel if the plan has one). */
 int ldmseg_bench_igemm(const float* x, const float* x2, const float* w, const float* bias, const float* resid,

@@ -174,6 +174,7 @@ struct WeightMap {
 struct ConvW {
   void* w = nullptr;      // [N][taps*cin_pad]
   float* bias = nullptr;  // [N]
+  float* c1 = nullptr;    // [N] row sums of w when a LayerNorm is folded into this GEMM (IgemmParams::c1), else null
   int N = 0, n_valid = 0, cin_pad = 0, taps = 1, cout = 0;
 };
 struct NormW { float* g = nullptr; float* b = nullptr; int C = 0; };
@@ -330,6 +331,14 @@ struct Exec {
     return launch_groupnorm(g, dt, s);
   }
 
+  // LayerNorm statistics only (the normalisation itself is folded into the consuming GEMM)
+  int rowstats(const Act& x, float eps, float* stats) {
+    const int M = B * x.H * x.W;
+    ProfScope ps(3, s, 0, 1.0 * M * x.C * esize(dt), dry());
+    if (dry()) return 0;
+    return launch_rowstats(x.p, stats, M, x.C, eps, dt, s);
+  }
+
   int layernorm(const NormW& n, const Act& x, float eps, int silu, Act* out, bool inplace = false) {
     *out = inplace ? x : new_act(x.C, x.H, x.W, false);
     const int M = B * x.H * x.W;
@@ -411,19 +420,33 @@ int build_transformer(Builder& b, const std::string& p, int C, TransformerW* t) 
   TRY(b.conv(p + "proj_in", C, C, 1, C, &t->proj_in));
   const std::string tb = p + "transformer_blocks.0.";
   TRY(b.norm(tb + "norm1", C, &t->ln1));
-  // fused q|k|v projection, no bias
+  // fused q|k|v projection, no bias, with norm1 (LayerNorm) folded in: W' = gamma (.) W, c1 = rowsum(W'), bias = W beta
   {
     ConvW& q = t->qkv;
     q.N = 3 * C; q.n_valid = 3 * C; q.cin_pad = C; q.taps = 1; q.cout = 3 * C;
     TRY(b.arena->alloc(&q.w, (size_t)3 * C * C * esize(dt)));
+    std::vector<int> ident(C);
+    for (int r = 0; r < C; ++r) ident[r] = r;
+    int* dident;
+    TRY(b.upload_ints(ident, &dident));
+    void* tmp;
+    HIP_TRY(hipMalloc(&tmp, (size_t)3 * C * C * sizeof(float)));
+    b.temps.push_back(tmp);
     const char* names[3] = {"attn1.to_q.weight", "attn1.to_k.weight", "attn1.to_v.weight"};
     for (int i = 0; i < 3; ++i) {
       const float* w;
       TRY(b.wm->get(tb + names[i], (int64_t)C * C, &w));
-      TRY(launch_repack_conv(w, (char*)q.w + (size_t)i * C * C * esize(dt), C, C, 1, 1, C, C, dt, b.s));
+      TRY(launch_repack_rows_scaled(w, (char*)q.w + (size_t)i * C * C * esize(dt), dident, C, C, t->ln1.g, dt, b.s));
+      TRY(launch_repack_rows_scaled(w, (char*)tmp + (size_t)i * C * C * sizeof(float), dident, C, C, t->ln1.b, DT_F32, b.s));
       b.nparams += (int64_t)C * C;
     }
-    q.bias = nullptr;
+    void *pc1, *pc2;
+    TRY(b.arena->alloc(&pc1, (size_t)3 * C * sizeof(float)));
+    TRY(b.arena->alloc(&pc2, (size_t)3 * C * sizeof(float)));
+    TRY(launch_rowsum(q.w, nullptr, (float*)pc1, 3 * C, C, dt, b.s));
+    TRY(launch_rowsum(tmp, nullptr, (float*)pc2, 3 * C, C, DT_F32, b.s));
+    q.c1 = (float*)pc1;
+    q.bias = (float*)pc2;
   }
   TRY(b.conv(tb + "attn1.to_out.0", C, C, 1, C, &t->attn_out));
   TRY(b.norm(tb + "norm3", C, &t->ln3));
@@ -442,12 +465,22 @@ int build_transformer(Builder& b, const std::string& p, int C, TransformerW* t) 
     const float *w, *bias;
     TRY(b.wm->get(tb + "ff.net.0.proj.weight", (int64_t)N * C, &w));
     TRY(b.wm->get(tb + "ff.net.0.proj.bias", N, &bias));
+    // norm3 (LayerNorm) folded in: W' = gamma (.) W in the packed row order, c1 = rowsum(W'), bias = W beta + b
     TRY(b.arena->alloc(&f.w, (size_t)N * C * esize(dt)));
-    TRY(launch_repack_rows(w, f.w, dmap, N, C, dt, b.s));
-    void* pb;
+    TRY(launch_repack_rows_scaled(w, f.w, dmap, N, C, t->ln3.g, dt, b.s));
+    void* tmp;
+    HIP_TRY(hipMalloc(&tmp, (size_t)N * C * sizeof(float)));
+    b.temps.push_back(tmp);
+    TRY(launch_repack_rows_scaled(w, tmp, dmap, N, C, t->ln3.b, DT_F32, b.s));
+    void *pb, *pc1, *pc2;
     TRY(b.arena->alloc(&pb, N * sizeof(float)));
     TRY(launch_repack_rows(bias, pb, dmap, N, 1, DT_F32, b.s));
-    f.bias = (float*)pb;
+    TRY(b.arena->alloc(&pc1, N * sizeof(float)));
+    TRY(b.arena->alloc(&pc2, N * sizeof(float)));
+    TRY(launch_rowsum(f.w, nullptr, (float*)pc1, N, C, dt, b.s));
+    TRY(launch_rowsum(tmp, (const float*)pb, (float*)pc2, N, C, DT_F32, b.s));
+    f.c1 = (float*)pc1;
+    f.bias = (float*)pc2;
     b.nparams += (int64_t)N * C + N;
   }
   TRY(b.conv(tb + "ff.net.2", C, 4 * C, 1, 4 * C, &t->ff2));
@@ -557,11 +590,21 @@ int run_transformer(Exec& ex, const TransformerW& t, const Act& x, Act* out) {
   Workspace* ws = ex.ws;
   const size_t m = ws->mark();
   const int C = t.C, N = x.H * x.W, M = ex.B * N;
-  Act n, h, ln, qkv, att, ff;
+  Act n, h, qkv, att, ff;
   TRY(ex.groupnorm(t.norm, x, nullptr, 1e-6f, 0, &n));
   TRY(ex.conv(t.proj_in, n, nullptr, &h, 1, 0, false, nullptr, 0, nullptr));
-  TRY(ex.layernorm(t.ln1, h, 1e-5f, 0, &ln));
-  TRY(ex.conv(t.qkv, ln, nullptr, &qkv, 1, 0, false, nullptr, 0, nullptr));
+  // norm1 is folded into the q|k|v GEMM: one statistics pass over h (mean, rstd per token), the GEMM reads h itself
+  float* stats = (float*)ws->scratch((size_t)M * 2 * sizeof(float));
+  TRY(ex.rowstats(h, 1e-5f, stats));
+  qkv = ex.new_act(3 * C, x.H, x.W, false);
+  {
+    IgemmParams p;
+    p.src0 = h.p; p.C0 = C; p.B = ex.B; p.Hi = p.Ho = x.H; p.Wi = p.Wo = x.W;
+    p.M = M; p.N = t.qkv.N; p.n_valid = 3 * C; p.W = t.qkv.w; p.bias = t.qkv.bias;
+    p.rowstats = stats; p.c1 = t.qkv.c1;
+    p.out = qkv.p; p.ldo = 3 * C;
+    TRY(ex.igemm(p));
+  }
   att = ex.new_act(C, x.H, x.W, false);
   {
     const double d = C / 8.0;
@@ -577,12 +620,13 @@ int run_transformer(Exec& ex, const TransformerW& t, const Act& x, Act* out) {
     p.resid = h.p; p.ldr = C; p.out = h.p; p.ldo = C;
     TRY(ex.igemm(p));
   }
-  TRY(ex.layernorm(t.ln3, h, 1e-5f, 0, &ln, false));
+  TRY(ex.rowstats(h, 1e-5f, stats));          // norm3, folded into the GEGLU GEMM the same way
   ff = ex.new_act(4 * C, x.H, x.W, false);
   {
     IgemmParams p;
-    p.src0 = ln.p; p.C0 = C; p.B = ex.B; p.Hi = p.Ho = x.H; p.Wi = p.Wo = x.W;
+    p.src0 = h.p; p.C0 = C; p.B = ex.B; p.Hi = p.Ho = x.H; p.Wi = p.Wo = x.W;
     p.M = M; p.N = t.ff1.N; p.n_valid = 4 * C; p.W = t.ff1.w; p.bias = t.ff1.bias;
+    p.rowstats = stats; p.c1 = t.ff1.c1;
     p.out = ff.p; p.ldo = 4 * C; p.epi = EPI_GEGLU;
     TRY(ex.igemm(p));
   }

@@ -113,7 +113,11 @@ constexpr bool epi_stage_dedicated() { return epi_stage_bytes<BM, BN, WAVES_M, W
 // Per K tile every wave: issues the DMA of stream position +NST-1 into the stage read one tile ago,
 // computes the current tile, waits with a COUNTED vmcnt until the next tile has landed (later ones
 // stay in flight) and passes the single barrier.
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int NST, bool PIPE, int LDR>
+// LNF: the launch carries a folded LayerNorm (IgemmParams::rowstats / c1).  A separate instantiation, because the extra
+// epilogue code is not free for the launches that do not use it: these kernels are ~55 KB of code each, short launches
+// run their epilogue cold out of HBM (1.6 GB of weights stream through L2 per forward), and the 64-row-tile 1x1 GEMMs
+// measured +10 us per launch with the LayerNorm branch merely present.
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int NST, bool PIPE, int LDR, bool LNF>
 __global__ __launch_bounds__((WAVES_M * WAVES_N + LDR) * 64, (WAVES_M * WAVES_N + LDR) > 8 ? 3 : 2) void igemm_kernel(const IgemmParams p) {   // <=256 regs at 2 waves/SIMD; 12-wave workgroups (8 compute + 4 loader waves) need 3 per SIMD: <=168
   constexpr int NW = WAVES_M * WAVES_N;   // 4 waves (128-row tiles, 2 workgroups/CU) or 8 (256-row tiles)
   static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
@@ -322,6 +326,11 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LDR) * 64, (WAVES_M * WAVES_N 
     f32x4 bv[NF];
 #pragma unroll
     for (int a = 0; a < NF; ++a) bv[a] = *(const f32x4*)(biasp + nl + a * 16);
+    f32x4 c1v[LNF ? NF : 1];
+    if constexpr (LNF) {
+#pragma unroll
+      for (int a = 0; a < NF; ++a) c1v[a] = *(const f32x4*)(p.c1 + nl + a * 16);
+    }
     // One 16-row block of the wave's tile.  BI = accumulator slot that holds it.
     auto row_block = [&](int b, auto bidx) __attribute__((always_inline)) {
       constexpr int BI = decltype(bidx)::value;
@@ -330,7 +339,12 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LDR) * 64, (WAVES_M * WAVES_N 
       {
         const int m = mb + lq;
         const int bimg = (m < p.M ? m : p.M - 1) / HWo;
-        if (p.rowbias) {                                   // time-embedding row of this pixel's image
+        if constexpr (LNF) {                               // folded LayerNorm: rstd * (acc - mean * c1) + c2
+          const float2 st = *(const float2*)(p.rowstats + (size_t)(m < p.M ? m : p.M - 1) * 2);
+#pragma unroll
+          for (int a = 0; a < NF; ++a)
+            *(f32x4*)(stg + lq * SROW + (a * 16 + lg * 4) * 4) = (acc[a][BI] - c1v[a] * st.x) * st.y + bv[a];
+        } else if (p.rowbias) {                                   // time-embedding row of this pixel's image
           const float* rbp = p.rowbias + (size_t)bimg * p.rb_stride + nl;
           f32x4 rb[NF];
 #pragma unroll
@@ -415,14 +429,26 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LDR) * 64, (WAVES_M * WAVES_N 
       f32x4 bv[NF];
 #pragma unroll
       for (int a = 0; a < NF; ++a) bv[a] = *(const f32x4*)(biasp + nl + a * 16);
+      f32x4 c1v[LNF ? NF : 1];
+      if constexpr (LNF) {
+#pragma unroll
+        for (int a = 0; a < NF; ++a) c1v[a] = *(const f32x4*)(p.c1 + nl + a * 16);
+      }
       const int oc0 = (n0 + wn * WTN) >> 1;
       auto row_block = [&](int b, auto bidx) __attribute__((always_inline)) {
         constexpr int BI = decltype(bidx)::value;
         const int mb = m0 + wm * WTM + b * 16;
+        float2 st = make_float2(0.f, 1.f);                 // folded LayerNorm: rstd * (acc - mean * c1) + c2
+        if constexpr (LNF) st = *(const float2*)(p.rowstats + (size_t)(mb + lq < p.M ? mb + lq : p.M - 1) * 2);
 #pragma unroll
         for (int a = 0; a < NF; a += 2) {
-          const f32x4 av = acc[a][BI] + bv[a];
-          const f32x4 gv = acc[a + 1][BI] + bv[a + 1];
+          f32x4 av = acc[a][BI], gv = acc[a + 1][BI];
+          if constexpr (LNF) {
+            av = (av - c1v[a] * st.x) * st.y;
+            gv = (gv - c1v[a + 1] * st.x) * st.y;
+          }
+          av += bv[a];
+          gv += bv[a + 1];
           f32x4 o;
 #pragma unroll
           for (int r = 0; r < 4; ++r) o[r] = av[r] * gelu_erf_f(gv[r]);
@@ -465,17 +491,21 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LDR) * 64, (WAVES_M * WAVES_N 
     const int m = m0 + wm * WTM + b * 16 + (lane & 15);
     if (m >= p.M) continue;
     const int bimg = m / HWo;
+    float2 st = make_float2(0.f, 1.f);                     // folded LayerNorm: rstd * (acc - mean * c1) + c2
+    if constexpr (LNF) st = *(const float2*)(p.rowstats + (size_t)m * 2);
     if (p.epi == EPI_GEGLU) {
       if constexpr (NF % 2 == 0) {
 #pragma unroll
         for (int a = 0; a < NF; a += 2) {
           const int n = n0 + wn * WTN + a * 16 + lg * 4;
           const int oc = ((n0 + wn * WTN + a * 16) >> 1) + lg * 4;
+          f32x4 c1a = f32x4{0.f, 0.f, 0.f, 0.f}, c1g = c1a;
+          if constexpr (LNF) { c1a = *(const f32x4*)(p.c1 + n); c1g = *(const f32x4*)(p.c1 + n + 16); }
           float v[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float av = acc[a][b][r] + gbias[a][r];
-            const float gv = acc[a + 1][b][r] + gbias[a + 1][r];
+            const float av = (acc[a][b][r] - c1a[r] * st.x) * st.y + gbias[a][r];
+            const float gv = (acc[a + 1][b][r] - c1g[r] * st.x) * st.y + gbias[a + 1][r];
             v[r] = av * gelu_erf_f(gv);
           }
           T* o = (T*)p.out + (size_t)m * p.ldo + oc;
@@ -495,6 +525,11 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LDR) * 64, (WAVES_M * WAVES_N 
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = acc[a][b][r];
+      if constexpr (LNF) {
+        const f32x4 c1q = *(const f32x4*)(p.c1 + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (v[r] - c1q[r] * st.x) * st.y;
+      }
       if (p.bias) {
         const f32x4 bv = *(const f32x4*)(p.bias + n);
 #pragma unroll
@@ -789,7 +824,7 @@ int g_big = kDefaultPolicy;      // bit0: 8-wave 256-row tiles with a 3-stage ri
                      // bit2: lone 64-row 4-stage tiles; bit3: pipelined K loop on the 256-row tiles; bit4: 8-wave 128-row
                      // tiles (+ loader waves on long K); bit5: loader waves on the 256-row tiles (long K / GEGLU)
 
-template <typename T, int BM, int BN, int WM, int WN, int NST = 2, bool PIPE = false, int LDR = 0>
+template <typename T, int BM, int BN, int WM, int WN, int NST = 2, bool PIPE = false, int LDR = 0, bool LNF = false>
 int run(const IgemmParams& pin, hipStream_t s) {
   IgemmParams p = pin;
   p.dbg = g_dbg;
@@ -804,7 +839,7 @@ int run(const IgemmParams& pin, hipStream_t s) {
   const int grid_x = nwork < resident ? nwork : resident;
   const size_t lds = (size_t)NST * (BM + BN) * kRowBytes +
                      (epi_stage_dedicated<BM, BN, WM, WN>() ? epi_stage_bytes<BM, BN, WM, WN>() : 0);
-  auto kern = igemm_kernel<T, BM, BN, WM, WN, NST, PIPE, LDR>;
+  auto kern = igemm_kernel<T, BM, BN, WM, WN, NST, PIPE, LDR, LNF>;
   static bool attr_set[kMaxDev] = {};
   const int dev = cur_dev();
   if (!attr_set[dev]) {
@@ -812,7 +847,7 @@ int run(const IgemmParams& pin, hipStream_t s) {
     attr_set[dev] = true;
   }
   g_last = IgemmDispatch{(int)sizeof(T) == 2 ? DT_BF16 : DT_F32, BM, BN, WM, WN, NST, PIPE ? 1 : 0, LDR,
-                         p.splits > 1 ? p.splits : 1, grid_x};
+                         p.splits > 1 ? p.splits : 1, grid_x, LNF ? 1 : 0};
   if (g_log_on) g_log.insert(igemm_dispatch_name(g_last));
   hipLaunchKernelGGL(kern, dim3(grid_x), dim3((WM * WN + LDR) * 64), lds, s, p);
   if (p.splits > 1) {
@@ -832,8 +867,28 @@ inline bool mid8_ok(long t128, int splits) {
   return (g_big & 16) && items >= 160 && items <= 2 * (long)num_cus();
 }
 
+// Launches with a folded LayerNorm (norm1 -> q|k|v, norm3 -> GEGLU: K = C <= 1280, N a multiple of 160 or GEGLU's 128):
+// the same tile rules as dispatch() below, restricted to the instantiations those shapes can reach.
+template <typename T>
+int dispatch_ln(const IgemmParams& p, hipStream_t s) {
+  const bool geglu = p.epi == EPI_GEGLU;
+  if (!geglu && p.N % 160 != 0) return -2;
+  const int bn = geglu ? 128 : 160;
+  const long t256 = (long)((p.M + 255) / 256) * (p.N / bn);
+  const long t128 = (long)((p.M + 127) / 128) * (p.N / bn);
+  const long t64 = (long)((p.M + 63) / 64) * (p.N / bn);
+  if (t256 >= 240) {
+    if (geglu) return (g_big & 32) && sizeof(T) == 2 ? run<T, 256, 128, 4, 2, 3, true, 4, true>(p, s) : run<T, 256, 128, 4, 2, 3, true, 0, true>(p, s);
+    return run<T, 256, 160, 4, 2, 3, true, 0, true>(p, s);
+  }
+  if (!geglu && mid8_ok(t128, 1)) return run<T, 128, 160, 4, 2, 3, true, 0, true>(p, s);
+  if (t64 <= num_cus()) return geglu ? run<T, 64, 128, 2, 2, 4, false, 0, true>(p, s) : run<T, 64, 160, 2, 2, 4, false, 0, true>(p, s);
+  return geglu ? run<T, 64, 128, 2, 2, 2, false, 0, true>(p, s) : run<T, 64, 160, 2, 2, 2, false, 0, true>(p, s);
+}
+
 template <typename T>
 int dispatch(const IgemmParams& p, hipStream_t s) {
+  if (p.rowstats) return dispatch_ln<T>(p, s);
   const int bn = (p.epi == EPI_GEGLU) ? 128 : (p.N % 160 == 0 ? 160 : (p.N % 128 == 0 ? 128 : (p.N % 64 == 0 ? 64 : 32)));
   // fewer than ~1.5 workgroups per CU with 128-row tiles: halve the M tile (2 co-resident
   // workgroups per CU are what hides the per-K-tile barrier)
@@ -889,8 +944,8 @@ IgemmDispatch igemm_last_dispatch() { return g_last; }
 // "igemm<dtype,BM,BN,WM,WN,NST,PIPE,LDR>" + "/splitk" when the launch ran K slices (partial epilogue + finish kernel)
 std::string igemm_dispatch_name(const IgemmDispatch& d) {
   char buf[96];
-  std::snprintf(buf, sizeof buf, "igemm<%s,%d,%d,%d,%d,%d,%d,%d>%s", d.dtype == DT_BF16 ? "bf16" : "f32", d.bm, d.bn, d.wm, d.wn,
-                d.nst, d.pipe, d.ldr, d.splits > 1 ? "/splitk" : "");
+  std::snprintf(buf, sizeof buf, "igemm<%s,%d,%d,%d,%d,%d,%d,%d%s>%s", d.dtype == DT_BF16 ? "bf16" : "f32", d.bm, d.bn, d.wm, d.wn,
+                d.nst, d.pipe, d.ldr, d.lnf ? ",ln" : "", d.splits > 1 ? "/splitk" : "");
   return buf;
 }
 void igemm_log_enable(int on) { g_log_on = on != 0; if (on) g_log.clear(); }
@@ -911,7 +966,7 @@ int igemm_pick_bn(int n_real, int epi) {
 // Split-K plan for grids that would leave most of the 256 CUs idle (the 8x8 / 16x16 feature maps):
 // returns the number of K slices (1 = no split).  Mirrors dispatch()'s tile choice.
 int igemm_plan_splits(const IgemmParams& p, int dtype) {
-  if (p.epi != EPI_STORE) return 1;
+  if (p.epi != EPI_STORE || p.rowstats) return 1;
   const int bke = dtype == DT_BF16 ? 64 : 32;
   const int bn = p.N % 160 == 0 ? 160 : (p.N % 128 == 0 ? 128 : (p.N % 64 == 0 ? 64 : 32));
   const long tiles128 = (long)((p.M + 127) / 128) * (p.N / bn);
@@ -947,6 +1002,7 @@ int launch_igemm(const IgemmParams& p, int dtype, hipStream_t s) {
   if (p.n_valid % 4 != 0 && p.epi != EPI_NCHW_F32) return -2;
   if (p.epi == EPI_GEGLU && p.N % 128 != 0) return -2;
   if (p.splits > 1 && (p.epi != EPI_STORE || p.partial == nullptr)) return -2;
+  if (p.rowstats && (!p.c1 || p.rowbias || p.splits > 1 || (p.epi != EPI_STORE && p.epi != EPI_GEGLU))) return -2;
   return dtype == DT_BF16 ? dispatch<bf16_t>(p, s) : dispatch<float>(p, s);
 }
 

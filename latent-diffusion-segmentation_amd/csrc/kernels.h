@@ -36,6 +36,11 @@ struct IgemmParams {
   const float* bias = nullptr;   // [N] (packed order) or null
   const float* rowbias = nullptr;  // [B][rb_stride] per-image bias (time embedding) or null
   int rb_stride = 0;
+  // LayerNorm folded into the GEMM (transformer norm1 -> q|k|v, norm3 -> GEGLU): X is the un-normalised tensor, W holds
+  // gamma_k * W[n][k], c1[n] = sum_k W[n][k] of that packed matrix, bias[n] = sum_k beta_k W0[n][k] + b[n], and
+  // out = rstd_m * (acc - mean_m * c1[n]) + bias[n] with (mean_m, rstd_m) = rowstats[m] from launch_rowstats.
+  const float* rowstats = nullptr;   // [M][2] or null
+  const float* c1 = nullptr;         // [N]
   const void* resid = nullptr;   // [M][ldr] residual, compute dtype, may alias out
   int ldr = 0;
   void* out = nullptr;
@@ -62,7 +67,7 @@ void igemm_set_dbg(int flags);
 int igemm_get_dbg();       // current (policy << 8) | ablation flags
 int igemm_default_dbg();   // the shipped value
 // template instantiation + plan of the most recent launch_igemm (test introspection)
-struct IgemmDispatch { int dtype, bm, bn, wm, wn, nst, pipe, ldr, splits, grid; };
+struct IgemmDispatch { int dtype, bm, bn, wm, wn, nst, pipe, ldr, splits, grid, lnf; };
 IgemmDispatch igemm_last_dispatch();
 std::string igemm_dispatch_name(const IgemmDispatch& d);
 void igemm_log_enable(int on);      // start (and clear) / stop recording the distinct instantiations launched
@@ -88,6 +93,14 @@ int launch_layernorm(const void* x, void* y, const float* gamma, const float* be
 
 // self-attention on fused qkv [B, N, 3C] (q | k | v, channel = head*d + i) -> out [B, N, C]
 int launch_attention(const void* qkv, void* out, int B, int N, int C, int heads, int dtype, hipStream_t s);
+
+// per-row (mean, rstd) of [M][C] (LayerNorm statistics, two-pass centred variance) -> stats [M][2] f32
+int launch_rowstats(const void* x, float* stats, int M, int C, float eps, int dtype, hipStream_t s);
+// out[r][k] = colscale[k] * (src_row[r] >= 0 ? w[src_row[r]][k] : 0)   (colscale null = 1)
+int launch_repack_rows_scaled(const float* w, void* out, const int* src_row_dev, int Npad, int K, const float* colscale,
+                              int dtype, hipStream_t s);
+// out[n] = sum_k W[n][k] (+ add[n]) over a packed [N][K] matrix in `dtype`, fp32 accumulation
+int launch_rowsum(const void* W, const float* add, float* out, int N, int K, int dtype, hipStream_t s);
 
 // NCHW f32 [B,C,HW] -> NHWC compute dtype [B,HW,Cpad] (zero padded channels), optional affine a*x+b
 int launch_pack_nchw(const float* x, void* y, int B, int C, int HW, int Cpad, float mul, float add,

@@ -205,6 +205,27 @@ __global__ void repack_rows_kernel(const float* w, T* out, const int* src_row, i
   }
 }
 template <typename T>
+__global__ void repack_rows_scaled_kernel(const float* w, T* out, const int* src_row, int Npad, int K, const float* colscale) {
+  const size_t total = (size_t)Npad * K;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int k = (int)(i % K);
+    const int r = (int)(i / K);
+    const int sr = src_row[r];
+    const float v = sr >= 0 ? w[(size_t)sr * K + k] : 0.f;
+    out[i] = from_f32<T>(colscale ? v * colscale[k] : v);
+  }
+}
+// one wave per row: out[n] = sum_k W[n][k] (+ add[n])
+template <typename T>
+__global__ __launch_bounds__(256) void rowsum_kernel(const T* W, const float* add, float* out, int N, int K) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int k = lane; k < K; k += 64) s += to_f32<T>(W[(size_t)n * K + k]);
+  s = wave64_sum(s);
+  if (lane == 0) out[n] = s + (add ? add[n] : 0.f);
+}
+template <typename T>
 __global__ void repack_convt2_kernel(const float* w, T* out, int Ci, int Co) {
   const size_t total = (size_t)4 * Co * Ci;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -343,6 +364,24 @@ int launch_repack_rows(const float* w, void* out, const int* src_row_dev, int Np
     hipLaunchKernelGGL(repack_rows_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, w, (bf16_t*)out, src_row_dev, Npad, K);
   else
     hipLaunchKernelGGL(repack_rows_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, w, (float*)out, src_row_dev, Npad, K);
+  return ok();
+}
+
+int launch_repack_rows_scaled(const float* w, void* out, const int* src_row_dev, int Npad, int K, const float* colscale,
+                              int dtype, hipStream_t s) {
+  const size_t total = (size_t)Npad * K;
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(repack_rows_scaled_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, w, (bf16_t*)out, src_row_dev, Npad, K, colscale);
+  else
+    hipLaunchKernelGGL(repack_rows_scaled_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, w, (float*)out, src_row_dev, Npad, K, colscale);
+  return ok();
+}
+
+int launch_rowsum(const void* W, const float* add, float* out, int N, int K, int dtype, hipStream_t s) {
+  if (dtype == DT_BF16)
+    hipLaunchKernelGGL(rowsum_kernel<bf16_t>, dim3((N + 3) / 4), dim3(256), 0, s, (const bf16_t*)W, add, out, N, K);
+  else
+    hipLaunchKernelGGL(rowsum_kernel<float>, dim3((N + 3) / 4), dim3(256), 0, s, (const float*)W, add, out, N, K);
   return ok();
 }
 

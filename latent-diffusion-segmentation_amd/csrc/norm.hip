@@ -249,9 +249,11 @@ __device__ __forceinline__ float wave_sum(float v) { return wave64_sum(v); }
 // Each wave keeps gamma/beta of its channel vectors in registers and walks rows in batches of RPW
 // (all RPW row loads are issued before the first reduction, so several KB per wave are in flight);
 // C*sizeof(T)/16 <= 64*VPL chunks per row.
-template <typename T, int VPL, int RPW>
+// STATS: only the row statistics are wanted (LayerNorm folded into the consuming GEMM, see IgemmParams::rowstats):
+// y, gamma, beta are unused and (mean, rstd) go to stats[row] - half the traffic of the normalising form.
+template <typename T, int VPL, int RPW, bool STATS = false>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* x, T* y, const float* gamma, const float* beta,
-                                                        int M, int C, float eps, int silu) {
+                                                        int M, int C, float eps, int silu, float* stats = nullptr) {
   constexpr int PC = Chunk<T>::N;
   const int lane = threadIdx.x & 63;
   const int nvec = C / PC;
@@ -261,8 +263,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* x, T* y, const 
     const int v = lane + k * 64;
 #pragma unroll
     for (int e = 0; e < PC; ++e) {
-      g[k][e] = v < nvec ? gamma[v * PC + e] : 0.f;
-      bt[k][e] = v < nvec ? beta[v * PC + e] : 0.f;
+      g[k][e] = (!STATS && v < nvec) ? gamma[v * PC + e] : 0.f;
+      bt[k][e] = (!STATS && v < nvec) ? beta[v * PC + e] : 0.f;
     }
   }
   const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -298,6 +300,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* x, T* y, const 
         }
       }
       const float rstd = 1.0f / sqrtf(wave_sum(q) * invC + eps);
+      if constexpr (STATS) {
+        if (lane == 0) *(float2*)(stats + (size_t)(row0 + r) * 2) = make_float2(mean, rstd);
+        continue;
+      }
 #pragma unroll
       for (int k = 0; k < VPL; ++k) {
         const int v = lane + k * 64;
@@ -559,7 +565,33 @@ int run_ln(const void* x, void* y, const float* g, const float* b, int M, int C,
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
+template <typename T>
+int run_rowstats(const void* x, float* stats, int M, int C, float eps, hipStream_t s) {
+  constexpr int PC = Chunk<T>::N;
+  if (C % PC != 0) return -2;
+  const int vpl = (C / PC + 63) / 64;
+  dim3 block(256);
+  auto grid_for_rpw = [&](int rpw) {
+    int blocks = (M + 4 * rpw - 1) / (4 * rpw);
+    if (blocks > 2048) blocks = 2048;
+    return dim3(blocks < 1 ? 1 : blocks);
+  };
+  const T* xp = (const T*)x;
+  switch (vpl) {
+    case 1: hipLaunchKernelGGL((layernorm_kernel<T, 1, 4, true>), grid_for_rpw(4), block, 0, s, xp, (T*)nullptr, nullptr, nullptr, M, C, eps, 0, stats); break;
+    case 2: hipLaunchKernelGGL((layernorm_kernel<T, 2, 4, true>), grid_for_rpw(4), block, 0, s, xp, (T*)nullptr, nullptr, nullptr, M, C, eps, 0, stats); break;
+    case 3: hipLaunchKernelGGL((layernorm_kernel<T, 3, 2, true>), grid_for_rpw(2), block, 0, s, xp, (T*)nullptr, nullptr, nullptr, M, C, eps, 0, stats); break;
+    case 4: case 5: hipLaunchKernelGGL((layernorm_kernel<T, 5, 2, true>), grid_for_rpw(2), block, 0, s, xp, (T*)nullptr, nullptr, nullptr, M, C, eps, 0, stats); break;
+    default: return -2;
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
 }  // namespace
+
+int launch_rowstats(const void* x, float* stats, int M, int C, float eps, int dtype, hipStream_t s) {
+  return dtype == DT_BF16 ? run_rowstats<bf16_t>(x, stats, M, C, eps, s) : run_rowstats<float>(x, stats, M, C, eps, s);
+}
 
 int gn_nchunk(int B, int HW) {
   // ~512-1024 workgroups in total, at least 8 pixels per chunk

@@ -360,4 +360,51 @@ int ldmseg_bench_attention(const float* qkv, int B, int N, int C, int heads, int
   return 0;
 }
 
+// F.linear(F.layer_norm(x, (K,), gamma, beta, eps), w, bias) - or the GEGLU feed-forward half on the normalised input when
+// geglu = 1 - computed the way the engine computes norm1 -> q|k|v and norm3 -> ff.net.0: statistics pass + GEMM on the raw x
+// with the LayerNorm folded into weights and epilogue (IgemmParams::rowstats).  x [M,K], w [N,K], out [M, N or N/2], f32.
+int ldmseg_op_ln_linear(const float* x, const float* gamma, const float* beta, const float* w, const float* bias, int M, int K,
+                        int N, float eps, int geglu, int dtype, float* out, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  Temp t;
+  if (K % bke(dtype)) return -2;
+  void* xp = t.get((size_t)M * K * es(dtype));
+  to_dev_dtype(x, xp, (size_t)M * K, dtype, s);
+  const int epi = geglu ? EPI_GEGLU : EPI_STORE;
+  const int bn = igemm_pick_bn(N, epi);
+  const int Np = rupi(N, bn);
+  const int nout = geglu ? N / 2 : N;
+  std::vector<int> map(Np);
+  for (int r = 0; r < Np; ++r) {
+    if (geglu) { const int blk = r / 32, q = r % 32; map[r] = (q < 16) ? blk * 16 + q : nout + blk * 16 + (q - 16); }
+    else map[r] = r < N ? r : -1;
+  }
+  int* dmap = (int*)t.get(Np * sizeof(int));
+  (void)hipMemcpy(dmap, map.data(), Np * sizeof(int), hipMemcpyHostToDevice);
+  void* wp = t.get((size_t)Np * K * es(dtype));
+  void* wb = t.get((size_t)Np * K * sizeof(float));
+  float* pb = (float*)t.get(Np * sizeof(float));
+  float* c1 = (float*)t.get(Np * sizeof(float));
+  float* c2 = (float*)t.get(Np * sizeof(float));
+  (void)hipMemsetAsync(pb, 0, Np * sizeof(float), s);
+  if (launch_repack_rows_scaled(w, wp, dmap, Np, K, gamma, dtype, s)) return -3;
+  if (launch_repack_rows_scaled(w, wb, dmap, Np, K, beta, DT_F32, s)) return -3;
+  if (bias && launch_repack_rows(bias, pb, dmap, Np, 1, DT_F32, s)) return -3;
+  if (launch_rowsum(wp, nullptr, c1, Np, K, dtype, s)) return -3;
+  if (launch_rowsum(wb, pb, c2, Np, K, DT_F32, s)) return -3;
+  float* stats = (float*)t.get((size_t)M * 2 * sizeof(float));
+  if (launch_rowstats(xp, stats, M, K, eps, dtype, s)) return -3;
+  void* op = t.get((size_t)M * nout * es(dtype));
+  IgemmParams p;
+  p.src0 = xp; p.C0 = K; p.B = 1; p.Hi = p.Ho = M; p.Wi = p.Wo = 1;
+  p.M = M; p.N = Np; p.n_valid = nout; p.W = wp; p.bias = c2; p.rowstats = stats; p.c1 = c1;
+  p.out = op; p.ldo = nout; p.epi = epi;
+  const int sp = igemm_plan_splits(p, dtype);
+  if (sp > 1) { p.splits = sp; p.partial = (float*)t.get((size_t)sp * M * Np * sizeof(float)); }
+  const int r = launch_igemm(p, dtype, s);
+  if (r) return r;
+  from_dev_dtype(op, out, (size_t)M * nout, dtype, s);
+  return 0;
+}
+
 }  // extern "C"

@@ -85,6 +85,7 @@ SIGNATURES = {
     "ldmseg_op_convt2": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "ldmseg_op_bilinear2x": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "ldmseg_op_igemm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "ldmseg_op_ln_linear": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _i, _vp, _vp]),
     "ldmseg_bench_igemm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
                                 C.POINTER(C.c_float), _vp]),
     "ldmseg_bench_attention": (_i, [_vp, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_float), _vp]),
@@ -106,6 +107,8 @@ def lib():
                 "Run `python __graft_entry__.py build` or `python -m ldmseg_amd.build`.")
         h = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
+            if os.environ.get("LDMSEG_HIP_LIB") and not hasattr(h, name):
+                continue                   # an older build loaded for an A/B measurement may lack newer test hooks
             fn = getattr(h, name)          # AttributeError if the export is missing
             fn.restype = res
             fn.argtypes = args

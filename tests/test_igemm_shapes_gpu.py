@@ -138,6 +138,42 @@ def test_unet_layer_shape_vs_oracle(L, dt, case):
     assert rel_err(out, ref) < (8e-3 if dt == BF16 else 1e-4), (case, name)
 
 
+LN_SHAPES = [   # (M, K = C, N, geglu): norm1 -> q|k|v and norm3 -> ff.net.0.proj of every transformer level at B = 8
+    (32768, 320, 960, 0), (32768, 320, 2560, 1), (8192, 640, 1920, 0), (8192, 640, 5120, 1),
+    (2048, 1280, 3840, 0), (2048, 1280, 10240, 1), (512, 1280, 3840, 0), (512, 1280, 10240, 1),
+]
+
+
+@pytest.mark.parametrize("dt", [BF16, F32])
+@pytest.mark.parametrize("M,K,N,geglu", LN_SHAPES)
+def test_unet_layernorm_folded_gemm_vs_oracle(L, dt, M, K, N, geglu):
+    """LayerNorm -> Linear / GEGLU of the transformer blocks as the engine runs them: one statistics pass, then the GEMM
+    on the un-normalised tokens with gamma folded into the weights and rstd*(acc - mean*c1) + c2 in the epilogue (its own
+    template instantiations, ',ln').  Reference: F.layer_norm + F.linear (+ GEGLU); the tokens carry a large common offset
+    (mean 3, std 1.5) so the mean cancellation of the epilogue is exercised."""
+    torch.set_num_threads(32)
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=g) * 1.5 + 3.0
+    gamma = 1 + 0.2 * torch.randn(K, generator=g)
+    beta = 0.2 * torch.randn(K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    xr = bf16_round(x) if dt == BF16 else x
+    y = F.linear(F.layer_norm(xr, (K,), gamma, beta, 1e-5), w, b)
+    if geglu:
+        a, gate = y.chunk(2, -1)
+        y = a * F.gelu(gate)
+    out = torch.empty(y.shape, device="cuda")
+    dx, dg, db, dw, dbias = dev(x), dev(gamma), dev(beta), dev(w), dev(b)
+    assert L.lib().ldmseg_op_ln_linear(P(dx), P(dg), P(db), P(dw), P(dbias), M, K, N, 1e-5, geglu, dt, P(out), None) == 0
+    torch.cuda.synchronize()
+    name = L.igemm_last_kernel()
+    assert ",ln>" in name
+    SEEN[dt].add(name.split(" ")[0])
+    # bf16: gamma*W and the output are rounded to bf16 (the unfolded form rounds LN(x) and W instead)
+    assert rel_err(out, y) < (1.5e-2 if dt == BF16 else 1e-4), name
+
+
 @pytest.mark.parametrize("dt", [BF16, F32])
 def test_conv_out_shape_vs_oracle(L, dt):
     """conv_out: 320 -> 4 channels at 64x64, written straight to fp32 NCHW (EPI_NCHW_F32, the narrow-N tile)."""

@@ -168,6 +168,34 @@ def test_layernorm(L, dt, M, Cc, eps, silu):
 
 
 @pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("M,K,N,geglu", [
+    (77, 320, 960, 0), (100, 640, 5120, 1), (300, 1280, 3840, 0), (1, 320, 2560, 1),   # ragged M (the full-size shapes: test_igemm_shapes_gpu.py)
+])
+def test_layernorm_folded_into_linear(L, dt, M, K, N, geglu):
+    """LayerNorm -> Linear / GEGLU as the engine runs it (statistics pass + GEMM on the raw input, gamma folded into the
+    weights, rstd*(acc - mean*c1) + c2 epilogue) against F.layer_norm + F.linear; the inputs have a large common offset
+    (mean 3, std 1.5) so that the mean cancellation in the epilogue is exercised."""
+    torch.set_num_threads(32)
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=g) * 1.5 + 3.0
+    gamma = 1 + 0.2 * torch.randn(K, generator=g)
+    beta = 0.2 * torch.randn(K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    xr = bf16_round(x) if dt == BF16 else x
+    y = F.linear(F.layer_norm(xr, (K,), gamma, beta, 1e-5), w, b)
+    if geglu:
+        a, gate = y.chunk(2, -1)
+        y = a * F.gelu(gate)
+    out = torch.empty(y.shape, device="cuda")
+    dx, dg, db, dw, dbias = dev(x), dev(gamma), dev(beta), dev(w), dev(b)
+    assert L.lib().ldmseg_op_ln_linear(P(dx), P(dg), P(db), P(dw), P(dbias), M, K, N, 1e-5, geglu, dt, P(out), None) == 0
+    torch.cuda.synchronize()
+    # bf16: gamma*W and the output are rounded to bf16 (the unfolded form rounds LN(x) and W instead)
+    assert rel_err(out, y) < (1.5e-2 if dt == BF16 else 1e-4), L.igemm_last_kernel()
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
 @pytest.mark.parametrize("B,N,Cc", [(1, 256, 320), (2, 64, 320), (1, 1024, 320), (1, 256, 640), (2, 4, 1280),
                                     (1, 64, 1280), (1, 100, 640), (1, 320, 1280), (1, 4096, 320)])
 def test_attention(L, dt, B, N, Cc):
