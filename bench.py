@@ -392,8 +392,15 @@ def main():
         # BASELINE configs[4]: 1024x1024 -> 128x128x4 latents, batch 4 (N = 16384 tokens in the first attention level)
         r128 = timed(tr, 4, 128, 5)
         r128["whole_step_mfma_frac"] = r128["image_steps_per_s"] * FLOP_UNET[128] / PEAK_BF16
-        r128["attention_path"] = os.environ.get("LDMSEG_ATTN_PATH", "default")
+        r128["attention_path"] = "bf16 (attention3.hip)" if args.dtype == "bf16" else "fp32"
         extras["config4_1024px_b4_l128_" + args.dtype] = r128
+        if args.dtype == "bf16":                      # the fp8 MFMA attention path BASELINE configs[4] names
+            unet.set_attention_fp8(16384)
+            r8 = timed(tr, 4, 128, 5)
+            unet.set_attention_fp8(0)
+            r8["whole_step_mfma_frac"] = r8["image_steps_per_s"] * FLOP_UNET[128] / PEAK_BF16
+            r8["attention_path"] = "fp8 e4m3 operands on the 16384-token level (attention_fp8.hip), bf16 elsewhere"
+            extras["config4_1024px_b4_l128_fp8_attention"] = r8
         # BASELINE configs[3]: mask inpainting, batch 16, 50 % of the latents known
         def inpaint(tr_, rgbx, sx):
             gi = torch.Generator().manual_seed(7)

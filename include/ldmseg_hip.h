@@ -87,6 +87,11 @@ int ldmseg_unet_forward(ldmseg_unet* h, const float* x, const int64_t* t_dev, in
 int ldmseg_unet_forward_parts(ldmseg_unet* h, const float* latents, const float* rgb_latents, const float* cond,
                               const int64_t* t_dev, int t_count, int64_t t_host, int B, int L, float* out,
                               void* stream);
+/* bf16 mode only: run the self-attention of every level with at least `min_tokens` tokens (H*W) on the fp8 operand path
+ * (OCP e4m3 Q/K/V/P on v_mfma_f32_16x16x32_fp8_fp8, fp32 accumulation and statistics) - the "fp8 MFMA attention path" of
+ * the 1024x1024 configuration (128x128 latents: 16384 / 4096 tokens at head dims 40 / 80); 0 switches it off (default).
+ * The reference has no counterpart (its attention is whatever diffusers' processor does in fp32). */
+int ldmseg_unet_set_attention_fp8(ldmseg_unet* h, int min_tokens);
 /* Allocate everything forward / sample_loop need at (B, L) now (workspace + the sampler's eps and
  * self-condition buffers); may synchronise the device.  Optional: without it the first call at a new,
  * larger shape does the same lazily. */

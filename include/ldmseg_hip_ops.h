@@ -29,6 +29,11 @@ int ldmseg_op_layernorm(const float* x, const float* gamma, const float* beta, i
                         int dtype, float* out, void* stream);
 /* diffusers Attention core on fused qkv [B,N,3C] -> [B,N,C] */
 int ldmseg_op_attention(const float* qkv, int B, int N, int C, int heads, int dtype, float* out, void* stream);
+/* the same on the fp8 (e4m3) operand path of the bf16 mode (K/V pre-quantised, Q and P quantised in the kernel, fp32
+ * accumulation; head dim 40 or 80) - BASELINE configs[4].  time_iters > 0 additionally times that many launches (pre-pass
+ * + kernel) into *us_per_launch; out may be NULL then. */
+int ldmseg_op_attention_fp8(const float* qkv, int B, int N, int C, int heads, float* out, int time_iters, float* us_per_launch,
+                            void* stream);
 /* nn.ConvTranspose2d(Ci, Co, kernel_size=2, stride=2)  (vae.py:154) */
 int ldmseg_op_convt2(const float* x, const float* w, const float* bias, int B, int Ci, int H, int W, int Co, int dtype,
                      float* out, void* stream);

@@ -257,6 +257,7 @@ struct Exec {
   int dt;
   int B;
   hipStream_t s;
+  int attn_fp8_min_tokens = 0;
   bool dry() const { return ws->dry; }
 
   Act new_act(int C, int H, int W, bool persist) {
@@ -386,6 +387,7 @@ struct ldmseg_unet {
   // sampler state
   int plan_B = 0, plan_L = 0;
   size_t plan_persist = 0, plan_scratch = 0;
+  int attn_fp8_min_tokens = 0;   // > 0: bf16 mode runs attention levels with N >= this many tokens on the fp8 operand path
   float* cond = nullptr;   // [B,4,L,L] self-conditioning channel
   float* eps = nullptr;
   size_t loop_elems = 0;
@@ -610,7 +612,14 @@ int run_transformer(Exec& ex, const TransformerW& t, const Act& x, Act* out) {
     const double d = C / 8.0;
     ProfScope ps(1, ex.s, 4.0 * ex.B * 8 * (double)N * N * d, 4.0 * M * C * esize(ex.dt), ex.dry(),
                  "N=" + std::to_string(N) + " C=" + std::to_string(C));
-    if (!ex.dry()) TRY(launch_attention(qkv.p, att.p, ex.B, N, C, 8, ex.dt, ex.s));
+    const size_t kv8 = (ex.dt == DT_BF16 && ex.attn_fp8_min_tokens > 0 && N >= ex.attn_fp8_min_tokens)
+                           ? attention_fp8_scratch_bytes(ex.B, N, C, 8) : 0;
+    if (kv8) {                                     // long-context level on the fp8 operand path (BASELINE configs[4])
+      void* scratch = ws->scratch(kv8);
+      if (!ex.dry()) TRY(launch_attention_fp8(qkv.p, scratch, att.p, ex.B, N, C, 8, ex.s));
+    } else if (!ex.dry()) {
+      TRY(launch_attention(qkv.p, att.p, ex.B, N, C, 8, ex.dt, ex.s));
+    }
   }
   // h = to_out(att) + h  (in place on h)
   {
@@ -652,6 +661,7 @@ int unet_forward_impl(ldmseg_unet* u, const float* a, int Ca, const float* b, in
   Workspace* ws = &u->ws;
   ws->begin(dry, scratch_base);
   Exec ex{ws, u->dt, B, s};
+  ex.attn_fp8_min_tokens = u->attn_fp8_min_tokens;
   const int dt = u->dt;
 
   // --- time embedding: sinusoid -> MLP -> every resnet's time_emb_proj(SiLU(emb)) ---
@@ -1325,6 +1335,15 @@ static int loop_reserve(ldmseg_unet* h, size_t n) {
   HIP_TRY(hipMalloc((void**)&h->cond, n * sizeof(float)));
   HIP_TRY(hipMalloc((void**)&h->eps, n * sizeof(float)));
   h->loop_elems = n;
+  return 0;
+}
+
+int ldmseg_unet_set_attention_fp8(ldmseg_unet* h, int min_tokens) {
+  g_err.clear();
+  if (!h || min_tokens < 0) return fail(LDMSEG_E_ARG, "bad argument");
+  if (min_tokens > 0 && h->dt != DT_BF16) return fail(LDMSEG_E_ARG, "the fp8 attention path belongs to the bf16 perf mode");
+  h->attn_fp8_min_tokens = min_tokens;
+  h->plan_B = h->plan_L = 0;          // the workspace plan depends on it
   return 0;
 }
 

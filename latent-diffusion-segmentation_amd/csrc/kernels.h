@@ -102,6 +102,10 @@ int launch_repack_rows_scaled(const float* w, void* out, const int* src_row_dev,
 // out[n] = sum_k W[n][k] (+ add[n]) over a packed [N][K] matrix in `dtype`, fp32 accumulation
 int launch_rowsum(const void* W, const float* add, float* out, int N, int K, int dtype, hipStream_t s);
 
+// fp8 (e4m3) operand path of the bf16 attention for the long-context levels (attention_fp8.hip): head dims 40 / 80 only
+size_t attention_fp8_scratch_bytes(int B, int N, int C, int heads);
+int launch_attention_fp8(const void* qkv, void* kv8_scratch, void* out, int B, int N, int C, int heads, hipStream_t s);
+
 // NCHW f32 [B,C,HW] -> NHWC compute dtype [B,HW,Cpad] (zero padded channels), optional affine a*x+b
 int launch_pack_nchw(const float* x, void* y, int B, int C, int HW, int Cpad, float mul, float add,
                      int dtype, hipStream_t s);

@@ -407,4 +407,34 @@ int ldmseg_op_ln_linear(const float* x, const float* gamma, const float* beta, c
   return 0;
 }
 
+// the same attention on the fp8 (e4m3) operand path of the bf16 mode (attention_fp8.hip): head dim 40 or 80
+int ldmseg_op_attention_fp8(const float* qkv, int B, int N, int C, int heads, float* out, int time_iters, float* us_per_launch,
+                            void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  Temp t;
+  const size_t kv = attention_fp8_scratch_bytes(B, N, C, heads);
+  if (!kv) return -2;
+  void* qp = t.get((size_t)B * N * 3 * C * 2);
+  to_dev_dtype(qkv, qp, (size_t)B * N * 3 * C, DT_BF16, s);
+  void* op = t.get((size_t)B * N * C * 2);
+  void* kp = t.get(kv);
+  int r = launch_attention_fp8(qp, kp, op, B, N, C, heads, s);
+  if (r) return r;
+  if (time_iters > 0 && us_per_launch) {
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    for (int i = 0; i < 2; ++i) (void)launch_attention_fp8(qp, kp, op, B, N, C, heads, s);
+    (void)hipEventRecord(e0, s);
+    for (int i = 0; i < time_iters; ++i) (void)launch_attention_fp8(qp, kp, op, B, N, C, heads, s);
+    (void)hipEventRecord(e1, s);
+    (void)hipEventSynchronize(e1);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    *us_per_launch = 1e3f * ms / time_iters;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  }
+  if (out) from_dev_dtype(op, out, (size_t)B * N * C, DT_BF16, s);
+  return 0;
+}
+
 }  // extern "C"

@@ -60,6 +60,7 @@ SIGNATURES = {
     "ldmseg_add_noise": (_i, [_vp, _vp, _vp, _vp, _i, _f, _vp, _i, _sz, _vp]),
     "ldmseg_remove_noise": (_i, [_vp, _vp, _vp, _vp, _i, _f, _vp, _i, _sz, _vp]),
     "ldmseg_unet_reserve": (_i, [_vp, _i, _i]),
+    "ldmseg_unet_set_attention_fp8": (_i, [_vp, _i]),
     "ldmseg_sample_loop": (_i, [_vp, C.POINTER(SampleCfg), _vp, _vp, _i, _i, _vp, _vp]),
     "ldmseg_vae_image_create": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
     "ldmseg_vae_image_destroy": (None, [_vp]),
@@ -82,6 +83,7 @@ SIGNATURES = {
     "ldmseg_op_groupnorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp, _vp]),
     "ldmseg_op_layernorm": (_i, [_vp, _vp, _vp, _i, _i, _f, _i, _i, _vp, _vp]),
     "ldmseg_op_attention": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "ldmseg_op_attention_fp8": (_i, [_vp, _i, _i, _i, _i, _vp, _i, C.POINTER(C.c_float), _vp]),
     "ldmseg_op_convt2": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "ldmseg_op_bilinear2x": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "ldmseg_op_igemm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),

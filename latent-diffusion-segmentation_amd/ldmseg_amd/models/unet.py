@@ -70,6 +70,12 @@ class UNet(object):
             _lib.check(_lib.lib().ldmseg_unet_reserve(self._h, int(batch), int(latent_size)), "ldmseg_unet_reserve")
         return self
 
+    def set_attention_fp8(self, min_tokens: int = 4096):
+        """bf16 mode: run every self-attention level with at least `min_tokens` tokens on the fp8 (e4m3) operand path -
+        BASELINE configs[4], the 1024x1024 / 128x128-latent configuration.  0 switches it off."""
+        _lib.check(_lib.lib().ldmseg_unet_set_attention_fp8(self._h, int(min_tokens)), "ldmseg_unet_set_attention_fp8")
+        return self
+
     def eval(self):
         return self
 

@@ -168,7 +168,7 @@ def test_unet_layernorm_folded_gemm_vs_oracle(L, dt, M, K, N, geglu):
     assert L.lib().ldmseg_op_ln_linear(P(dx), P(dg), P(db), P(dw), P(dbias), M, K, N, 1e-5, geglu, dt, P(out), None) == 0
     torch.cuda.synchronize()
     name = L.igemm_last_kernel()
-    assert ",ln>" in name
+    assert ",ln" in name
     SEEN[dt].add(name.split(" ")[0])
     # bf16: gamma*W and the output are rounded to bf16 (the unfolded form rounds LN(x) and W instead)
     assert rel_err(out, y) < (1.5e-2 if dt == BF16 else 1e-4), name

@@ -394,6 +394,30 @@ def test_config_l128_b4_properties(unets):
     assert rel_err(u(x[1:2].contiguous(), t).sample, y1[1:2]) < 2e-2
 
 
+def test_config_l128_fp8_attention_vs_bf16(unet_sd):
+    """BASELINE configs[4]: the 1024x1024 configuration with the fp8 (e4m3) attention path on the 16384-token level against
+    the same forward with bf16 attention - the effect of the fp8 operands on the network output (real activations, not
+    unit-variance noise)."""
+    from ldmseg_amd.models import UNet
+    u = UNet(unet_sd, in_channels=12, device=DEV, compute_dtype="bf16")
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(2, 12, 128, 128, generator=g).to(DEV)
+    t = torch.tensor(259, device=DEV)
+    y16 = u(x, t).sample
+    u.set_attention_fp8(16384)
+    y8 = u(x, t).sample
+    assert torch.isfinite(y8).all() and torch.equal(u(x, t).sample, y8)
+    u.set_attention_fp8(4096)                               # also the 4096-token (head dim 80) level
+    y8b = u(x, t).sample
+    u.set_attention_fp8(0)
+    assert torch.equal(u(x, t).sample, y16)                 # switching it off restores the bf16 path bit for bit
+    l2 = float((y8 - y16).norm() / y16.norm())
+    l2b = float((y8b - y16).norm() / y16.norm())
+    print(f"fp8 attention in the L=128 forward: rel-L2 vs bf16 attention {l2:.3e} (16384-token level), {l2b:.3e} (+4096-token level)")
+    assert not torch.equal(y8, y16)
+    assert l2 < 5e-2 and l2b < 8e-2 and rel_err(y8, y16) < 0.15
+
+
 # ------------------------------------------------------------------ section 8(f) rank 3: bit codec + checkpoint readers
 def test_bitcodec_bit_exact_vs_reference_golden(golden):
     from ldmseg_amd.data import encode_bitmap, decode_bitmap
