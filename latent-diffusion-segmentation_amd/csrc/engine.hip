@@ -1466,7 +1466,9 @@ int ldmseg_profile_read(int family, int64_t* launches, double* total_ms, double*
 // tuning knobs for experiments: key 0 = igemm K-loop ring depth (2, 3, 4)
 int ldmseg_debug_set(int key, int value) {
   if (key == 2) { attention_set_qf1(value); return 0; }
-  if (key == 1) { igemm_set_dbg(value); return 0; }   // bits 0-7 ablation flags (LDMSEG_IGEMM_ABLATE builds), bits 8-12 tile policy
+  if (key == 1) { igemm_set_dbg(value); return 0; }
+  if (key == 5) { igemm_force_cfg(value); return 0; }   // tools/tune_igemm.py: entry of igemm's instantiation list, -1 = off
+  if (key == 6 || key == 7) { ops_bench_knob(key, value); return 0; }   // ldmseg_bench_igemm: 6 = weight copies rotated, 7 = folded-LN launch   // bits 0-7 ablation flags (LDMSEG_IGEMM_ABLATE builds), bits 8-12 tile policy
   static unsigned long long ts_ptr = 0;                // keys 3/4: low/high half of a device stamp buffer (ablate builds)
   if (key == 3) { ts_ptr = (ts_ptr & 0xffffffff00000000ull) | (unsigned)value; igemm_set_tsbuf((void*)(uintptr_t)ts_ptr); return 0; }
   if (key == 4) { ts_ptr = (ts_ptr & 0xffffffffull) | ((unsigned long long)(unsigned)value << 32); igemm_set_tsbuf((void*)(uintptr_t)ts_ptr); return 0; }

@@ -656,11 +656,13 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LDR) * 64, (WAVES_M * WAVES_N 
       // (with two workgroups per CU the co-resident one fills those gaps and this form measured slower)
       uint4 wfA[NF], xfA[MF], wfB[NF], xfB[MF];
 #define IGEMM_READ(WF, XF, STAGE, CO)                                                                  \
-  {                                                                                                    \
+  if (!DBG(p, 8)) {                                                                                    \
     const unsigned char* xs_ = smem + (STAGE) * kStageBytes + (wm * WTM) * kRowBytes + fr_row + (CO);  \
     const unsigned char* ws_ = smem + (STAGE) * kStageBytes + (BM + wn * WTN) * kRowBytes + fr_row + (CO); \
-    _Pragma("unroll") for (int a = 0; a < NF; ++a) WF[a] = *(const uint4*)(ws_ + a * 16 * kRowBytes);   \
+    /* W0, every X, then W1.. : the order the W-major MFMA batch first needs them */                     \
+    WF[0] = *(const uint4*)(ws_);                                                                        \
     _Pragma("unroll") for (int b = 0; b < MF; ++b) XF[b] = *(const uint4*)(xs_ + b * 16 * kRowBytes);   \
+    _Pragma("unroll") for (int a = 1; a < NF; ++a) WF[a] = *(const uint4*)(ws_ + a * 16 * kRowBytes);   \
   }
 #define IGEMM_MMA(WF, XF)                                                                              \
   if (!DBG(p, 4)) {                                                                                  \
@@ -670,15 +672,27 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LDR) * 64, (WAVES_M * WAVES_N 
     _Pragma("unroll") for (int a = 0; a < NF; ++a) asm volatile("" ::"v"(WF[a].x), "v"(WF[a].w));       \
     _Pragma("unroll") for (int b = 0; b < MF; ++b) asm volatile("" ::"v"(XF[b].x), "v"(XF[b].w));       \
   }
+      // Issue order of a half tile: one ds_read_b128 in front of every MPR MFMAs instead of all reads, then all MFMAs - the
+      // read burst of eight waves otherwise meets the loader waves' LDS-DMA writes at the same moment.  Model of this loop
+      // in tools/ubench/mfma_lds.hip: 908 -> 817 ns per K tile with L2-resident operands, 1306 -> 1158 ns from the MALL;
+      // the kernel: -6 % over the layer shapes, -8..10 % on the 3x3 convs.
+      constexpr int NMMA = NF * MF * (sizeof(T) == 2 ? 1 : 4);   // MFMA instructions per half tile (fp32: four 16x16x4 per k-group)
+      constexpr int MPR = NMMA / (NF + MF);
+#define IGEMM_INTERLEAVE                                                                                \
+  static_for<NF + MF>([&](auto) __attribute__((always_inline)) {                                        \
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                  \
+    __builtin_amdgcn_sched_group_barrier(0x008, MPR, 0);                                                \
+  });                                                                                                   \
+  __builtin_amdgcn_sched_group_barrier(0x008, NMMA - MPR * (NF + MF), 0);                               \
+  __builtin_amdgcn_sched_barrier(0);
       if (is_cmp) IGEMM_READ(wfA, xfA, cur, fr_c0)
       for (int kt = kb; kt < ke; ++kt) {
         bool more = false;
         if (is_ldr) more = DBG(p, 1) ? false : fetch_next(fst);
         if (is_cmp) {
           IGEMM_READ(wfB, xfB, cur, fr_c1)
-          __builtin_amdgcn_sched_barrier(0);
           IGEMM_MMA(wfA, xfA)
-          __builtin_amdgcn_sched_barrier(0);
+          IGEMM_INTERLEAVE
           // B is in registers, so nobody still reads this stage
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
@@ -690,14 +704,16 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LDR) * 64, (WAVES_M * WAVES_N 
         cur = (cur + 1 == NST) ? 0 : cur + 1;
         fst = (fst + 1 == NST) ? 0 : fst + 1;
         if (is_cmp) {
-          if (kt + 1 < ke) IGEMM_READ(wfA, xfA, cur, fr_c0)   // (an item's first A read follows its predecessor's epilogue)
-          __builtin_amdgcn_sched_barrier(0);
+          // (after an item's last tile this reads a stage that may not have landed: harmless, the next item re-reads its
+          // first A fragments after the epilogue - a conditional read would split the block and undo the interleaving)
+          IGEMM_READ(wfA, xfA, cur, fr_c0)
           IGEMM_MMA(wfB, xfB)
-          __builtin_amdgcn_sched_barrier(0);
+          IGEMM_INTERLEAVE
         }
       }
 #undef IGEMM_READ
 #undef IGEMM_MMA
+#undef IGEMM_INTERLEAVE
     } else {
     for (int kt = kb; kt < ke; ++kt) {
       const bool more = DBG(p, 1) ? false : fetch_next(fst);
@@ -824,6 +840,26 @@ int g_big = kDefaultPolicy;      // bit0: 8-wave 256-row tiles with a 3-stage ri
                      // bit2: lone 64-row 4-stage tiles; bit3: pipelined K loop on the 256-row tiles; bit4: 8-wave 128-row
                      // tiles (+ loader waves on long K); bit5: loader waves on the 256-row tiles (long K / GEGLU)
 
+int g_force_cfg = -1;            // tools/tune_igemm.py: run every launch with this entry of the instantiation list
+
+// Launch table measured on the MI355X (tools/tune_igemm.py): launch shape -> entry of the instantiation list in run_cfg()
+// + number of K slices.  Shapes that are not listed (other batch sizes, other models) use the rules in dispatch() /
+// igemm_plan_splits(); so does every launch while a non-default tile policy is set (tests, ablations).
+struct TunedEntry { int dtype, M, N, K, taps, stride, up, epi, lnf, cfg, splits; };
+const TunedEntry kTuned[] = {
+#include "igemm_tuned.inc"
+    {-1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
+
+const TunedEntry* tuned_lookup(const IgemmParams& p, int dtype) {
+  if (g_big != kDefaultPolicy || g_force_cfg >= 0) return nullptr;
+  const int K = p.taps * (p.C0 + p.C1), lnf = p.rowstats ? 1 : 0;
+  for (const TunedEntry* e = kTuned; e->dtype >= 0; ++e)
+    if (e->M == p.M && e->N == p.N && e->K == K && e->dtype == dtype && e->taps == p.taps && e->stride == p.stride &&
+        e->up == p.up && e->epi == p.epi && e->lnf == lnf)
+      return e;
+  return nullptr;
+}
+
 template <typename T, int BM, int BN, int WM, int WN, int NST = 2, bool PIPE = false, int LDR = 0, bool LNF = false>
 int run(const IgemmParams& pin, hipStream_t s) {
   IgemmParams p = pin;
@@ -867,6 +903,42 @@ inline bool mid8_ok(long t128, int splits) {
   return (g_big & 16) && items >= 160 && items <= 2 * (long)num_cus();
 }
 
+// The instantiation list the launch table indexes (BN and the LayerNorm fold follow from the launch): -2 = not in the list.
+//   0  256 rows, 8 compute + 4 loader waves      3  128 rows, 4 compute + 4 loader waves, 4-stage ring
+//   1  256 rows, 8 waves, pipelined K loop       4  128 rows, 8 waves, pipelined K loop
+//   2  256 rows, 8 waves, plain K loop           5  128 rows, 4 waves, 4-stage ring (one workgroup per CU)
+//   6  64 rows, 4 waves, 4-stage ring            7  64 rows, 4 waves, two workgroups per CU
+//   8  128 rows, 4 waves, two workgroups per CU
+constexpr int kNumCfg = 9;
+template <typename T, int BN, bool LNF>
+int run_cfg(int cfg, const IgemmParams& p, hipStream_t s) {
+  switch (cfg) {
+    case 0: return run<T, 256, BN, 4, 2, 3, true, 4, LNF>(p, s);
+    case 1: return run<T, 256, BN, 4, 2, 3, true, 0, LNF>(p, s);
+    case 4: return run<T, 128, BN, 4, 2, 3, true, 0, LNF>(p, s);
+    case 6: return run<T, 64, BN, 2, 2, 4, false, 0, LNF>(p, s);
+    case 7: return run<T, 64, BN, 2, 2, 2, false, 0, LNF>(p, s);
+    case 8: return run<T, 128, BN, 2, 2, 2, false, 0, LNF>(p, s);
+    default: break;
+  }
+  if constexpr (!LNF) {
+    switch (cfg) {
+      case 2: return run<T, 256, BN, 4, 2, 3, false>(p, s);
+      case 3: return run<T, 128, BN, 2, 2, 4, true, 4>(p, s);
+      case 5: return run<T, 128, BN, 2, 2, 4>(p, s);
+      default: break;
+    }
+  }
+  return -2;
+}
+template <typename T>
+int run_cfg_any(int cfg, const IgemmParams& p, hipStream_t s) {
+  const bool geglu = p.epi == EPI_GEGLU;
+  const int bn = geglu ? 128 : (p.N % 160 == 0 ? 160 : (p.N % 128 == 0 ? 128 : 0));
+  if (p.rowstats) return bn == 160 ? run_cfg<T, 160, true>(cfg, p, s) : bn == 128 ? run_cfg<T, 128, true>(cfg, p, s) : -2;
+  return bn == 160 ? run_cfg<T, 160, false>(cfg, p, s) : bn == 128 ? run_cfg<T, 128, false>(cfg, p, s) : -2;
+}
+
 // Launches with a folded LayerNorm (norm1 -> q|k|v, norm3 -> GEGLU: K = C <= 1280, N a multiple of 160 or GEGLU's 128):
 // the same tile rules as dispatch() below, restricted to the instantiations those shapes can reach.
 template <typename T>
@@ -888,6 +960,16 @@ int dispatch_ln(const IgemmParams& p, hipStream_t s) {
 
 template <typename T>
 int dispatch(const IgemmParams& p, hipStream_t s) {
+  {
+    int cfg = g_force_cfg;
+    if (cfg < 0) {
+      if (const TunedEntry* e = tuned_lookup(p, sizeof(T) == 2 ? DT_BF16 : DT_F32)) cfg = e->cfg;
+    }
+    if (cfg >= 0) {
+      const int r = run_cfg_any<T>(cfg, p, s);
+      if (r != -2 || g_force_cfg >= 0) return r;     // a forced entry that does not exist for this launch is an error
+    }
+  }
   if (p.rowstats) return dispatch_ln<T>(p, s);
   const int bn = (p.epi == EPI_GEGLU) ? 128 : (p.N % 160 == 0 ? 160 : (p.N % 128 == 0 ? 128 : (p.N % 64 == 0 ? 64 : 32)));
   // fewer than ~1.5 workgroups per CU with 128-row tiles: halve the M tile (2 co-resident
@@ -937,6 +1019,7 @@ int dispatch(const IgemmParams& p, hipStream_t s) {
 }  // namespace
 
 void igemm_set_tsbuf(void* b) { g_tsbuf = b; }
+void igemm_force_cfg(int cfg) { g_force_cfg = cfg; }
 void igemm_set_dbg(int f) { g_dbg = f & 0xff; g_big = (f >> 8) & 63; }   // bits 8-13 select the tile policy
 int igemm_get_dbg() { return (g_big << 8) | g_dbg; }
 int igemm_default_dbg() { return kDefaultPolicy << 8; }
@@ -967,6 +1050,7 @@ int igemm_pick_bn(int n_real, int epi) {
 // returns the number of K slices (1 = no split).  Mirrors dispatch()'s tile choice.
 int igemm_plan_splits(const IgemmParams& p, int dtype) {
   if (p.epi != EPI_STORE || p.rowstats) return 1;
+  if (const TunedEntry* e = tuned_lookup(p, dtype)) return e->splits;
   const int bke = dtype == DT_BF16 ? 64 : 32;
   const int bn = p.N % 160 == 0 ? 160 : (p.N % 128 == 0 ? 128 : (p.N % 64 == 0 ? 64 : 32));
   const long tiles128 = (long)((p.M + 127) / 128) * (p.N / bn);

@@ -64,6 +64,8 @@ int igemm_plan_splits(const IgemmParams& p, int dtype);
 void attention_set_qf1(int v);    // tuning knob: force 16 query rows per wave
 void igemm_set_tsbuf(void* dev_buf);   // LDMSEG_IGEMM_ABLATE builds only
 void igemm_set_dbg(int flags);
+void ops_bench_knob(int key, int value);   // ldmseg_bench_igemm (ops_api.hip): 6 = number of weight copies rotated, 7 = folded-LN launch
+void igemm_force_cfg(int cfg);   // tuning tool: >= 0 runs every launch with that entry of the instantiation list, -1 = off
 int igemm_get_dbg();       // current (policy << 8) | ablation flags
 int igemm_default_dbg();   // the shipped value
 // template instantiation + plan of the most recent launch_igemm (test introspection)

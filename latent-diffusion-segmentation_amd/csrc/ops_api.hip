@@ -245,6 +245,8 @@ int ldmseg_op_bilinear2x(const float* x, int B, int C, int H, int W, int dtype, 
 // bias, per-image bias row (time embedding), residual and SiLU, or the GEGLU epilogue.  Boundary tensors are NCHW f32:
 // x [B,Ci,H,W], x2 [B,Ci2,H,W] or NULL, w [Co,Ci+Ci2,k,k], resid [B,Cout,Ho,Wo] or NULL, rowbias [B,Co] or NULL,
 // out [B,Cout,Ho,Wo] with Cout = Co (Co/2 for GEGLU, whose w rows are [value | gate] like ff.net.0.proj).
+static int g_bench_rot = 1, g_bench_ln = 0;
+static inline bool sp_gt1(int sp) { return sp > 1; }
 static int op_igemm_impl(const float* x, const float* x2, const float* w, const float* bias, const float* resid,
                          const float* rowbias, int B, int Ci, int Ci2, int H, int W, int Co, int k, int stride, int up, int geglu,
                          int silu, int splits, int dtype, float* out, void* stream, int time_iters, float* us_per_launch) {
@@ -303,14 +305,34 @@ static int op_igemm_impl(const float* x, const float* x2, const float* w, const 
   p.resid = rp; p.ldr = cout; p.out = op; p.ldo = cout; p.epi = epi; p.silu = silu;
   int sp = splits > 0 ? splits : igemm_plan_splits(p, dtype);
   if (sp > 1) { p.splits = sp; p.partial = (float*)t.get((size_t)sp * p.M * Np * sizeof(float)); }
+  if (time_iters > 0 && g_bench_ln && !sp_gt1(sp) && !rowbias) {   // time the folded-LayerNorm instantiation (mean 0, rstd 1, c1 0)
+    float* st = (float*)t.get((size_t)p.M * 2 * sizeof(float));
+    float* c1z = (float*)t.get(Np * sizeof(float));
+    (void)hipMemsetAsync(c1z, 0, Np * sizeof(float), s);
+    std::vector<float> h((size_t)p.M * 2);
+    for (int m = 0; m < p.M; ++m) { h[2 * m] = 0.f; h[2 * m + 1] = 1.f; }
+    (void)hipMemcpy(st, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice);
+    p.rowstats = st; p.c1 = c1z;
+  }
   const int r = launch_igemm(p, dtype, s);
   if (r) return r;
   if (time_iters > 0 && us_per_launch) {        // kernel timing (tools/): launches back to back on the stream, HIP events around
+    // the weights of a layer are cold in the real forward (1.6 GB of them stream through per step): rotate over copies
+    const size_t wbytes = (size_t)Np * k * k * ct * es(dtype);
+    int rot = g_bench_rot < 1 ? 1 : g_bench_rot;
+    std::vector<const void*> wc(1, wp);
+    for (int i = 1; i < rot; ++i) {
+      void* c = t.get(wbytes);
+      if (!c) break;
+      (void)hipMemcpyAsync(c, wp, wbytes, hipMemcpyDeviceToDevice, s);
+      wc.push_back(c);
+    }
+    rot = (int)wc.size();
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    for (int i = 0; i < 3; ++i) (void)launch_igemm(p, dtype, s);
+    for (int i = 0; i < 3; ++i) { p.W = wc[i % rot]; (void)launch_igemm(p, dtype, s); }
     (void)hipEventRecord(e0, s);
-    for (int i = 0; i < time_iters; ++i) (void)launch_igemm(p, dtype, s);
+    for (int i = 0; i < time_iters; ++i) { p.W = wc[(i + 3) % rot]; (void)launch_igemm(p, dtype, s); }
     (void)hipEventRecord(e1, s);
     (void)hipEventSynchronize(e1);
     float ms = 0;
@@ -322,6 +344,14 @@ static int op_igemm_impl(const float* x, const float* x2, const float* w, const 
   return unpack_nhwc(op, out, B, cout, Ho * Wo, cout, dtype, s);
 }
 
+}  // extern "C"
+namespace ldmseg {
+void ops_bench_knob(int key, int value) {
+  if (key == 6) g_bench_rot = value;
+  if (key == 7) g_bench_ln = value;
+}
+}  // namespace ldmseg
+extern "C" {
 int ldmseg_op_igemm(const float* x, const float* x2, const float* w, const float* bias, const float* resid,
                     const float* rowbias, int B, int Ci, int Ci2, int H, int W, int Co, int k, int stride, int up, int geglu,
                     int silu, int splits, int dtype, float* out, void* stream) {

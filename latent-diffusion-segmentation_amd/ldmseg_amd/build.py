@@ -41,7 +41,7 @@ def build_library(force=False, verbose=False):
     hipcc = _hipcc()
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, h) for h in ("common.h", "kernels.h")]
+    headers = [os.path.join(CSRC, h) for h in ("common.h", "kernels.h", "igemm_tuned.inc")]
     headers += [os.path.join(INCLUDE, h) for h in ("ldmseg_hip.h", "ldmseg_hip_ops.h")]
     jobs = []
     objs = []

@@ -42,6 +42,8 @@ def igemm(case, dt="bf16", iters=20, B=8):
     res = torch.randn(B, cout, Ho, Ho, device="cuda") if use_res else None
     rb = torch.randn(B, Co, device="cuda") if use_rb else None
     us = C.c_float()
+    if os.environ.get("ROT"):        # weights rotated over copies so that they come from HBM like in the real forward
+        L.ldmseg_debug_set(6, max(1, min(24, (400 << 20) // (Co * ct * k * k * 2))))
     _lib.check(L.ldmseg_bench_igemm(P(x), P(x2), P(w), P(b), P(res), P(rb), B, Ci, Ci2, H, H, Co, k, stride, up, geglu, 0, 0,
                                     DT[dt], iters, C.byref(us), None), "bench_igemm")
     fl = 2.0 * B * Ho * Ho * Co * ct * k * k
@@ -60,6 +62,15 @@ if __name__ == "__main__":
             shapes = [(int(os.environ.get("B", 8)), int(sys.argv[2]), int(sys.argv[3]))]
         for s in shapes:
             attn(*s, dt=dt)
+    elif what == "igemm1":            # one shape of the list (PMC passes, ablations): kbench.py igemm1 <index> [ln]
+        from test_igemm_shapes_gpu import SHAPES
+        if os.environ.get("DBG"):
+            L.ldmseg_debug_set(1, int(os.environ["DBG"], 0))
+        if len(sys.argv) > 3:
+            L.ldmseg_debug_set(7, 1)
+        if os.environ.get("CFG"):
+            L.ldmseg_debug_set(5, int(os.environ["CFG"]))
+        igemm(SHAPES[int(sys.argv[2])], dt, iters=int(os.environ.get("ITERS", 20)))
     else:
         if os.environ.get("POLICY"):
             L.ldmseg_debug_set(1, int(os.environ["POLICY"]) << 8)

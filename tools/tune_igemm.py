@@ -1,0 +1,104 @@
+#!/usr/bin/env python
+"""Measure every entry of igemm's instantiation list x K-slice count on the UNet's launch shapes and write the launch table
+(csrc/igemm_tuned.inc) the dispatcher consults.  Tuning tool: run on the MI355X, product code never calls it.
+
+    python tools/tune_igemm.py [B=8] [L=64] [dtype=bf16] > gpurun_out/tune_B8_L64.log     # table -> gpurun_out/tuned_B8_L64_bf16.inc
+
+Timing: ldmseg_bench_igemm (HIP events around back-to-back launches) with the layer's weights rotated over enough copies to
+come from HBM like they do in the real forward (1.6 GB of weights per step); activations stay cache-warm, as they are
+when the producing kernel has just written them.  A shape enters the table only if its best entry beats the built-in rules
+by more than 3 %."""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, os.path.join(ROOT, "latent-diffusion-segmentation_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: E402
+from ldmseg_amd import _lib  # noqa: E402
+from test_igemm_shapes_gpu import SHAPES  # noqa: E402
+
+Lb = _lib.lib()
+P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+LAT = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+DTN = sys.argv[3] if len(sys.argv) > 3 else "bf16"
+DT = {"bf16": 1, "fp32": 0}[DTN]
+NCFG = 9
+ITERS = 30
+
+
+def bench(t, cfg, splits, ln):
+    x, x2, w, b, res, rb, (Ci, Ci2, H, Co, k, stride, up, geglu) = t
+    Lb.ldmseg_debug_set(5, cfg)
+    Lb.ldmseg_debug_set(7, 1 if ln else 0)
+    us = C.c_float()
+    r = Lb.ldmseg_bench_igemm(P(x), P(x2), P(w), P(b), P(res), P(rb), B, Ci, Ci2, H, H, Co, k, stride, up, geglu, 0, splits,
+                              DT, ITERS, C.byref(us), None)
+    Lb.ldmseg_debug_set(5, -1)
+    Lb.ldmseg_debug_set(7, 0)
+    return (us.value, _lib.igemm_last_kernel()) if r == 0 else (None, None)
+
+
+table = []
+tot_h = tot_b = 0.0
+for case in SHAPES:
+    H0, Ci, Ci2, Co, k, stride, up, geglu, use_res, use_rb = case
+    H = H0 * LAT // 64
+    if Ci < 64:
+        continue                      # conv_in: K is one padded tile, nothing to choose
+    ct = Ci + Ci2
+    ln = k == 1 and not Ci2 and not use_res and (geglu or Co == 3 * Ci)      # norm1 -> q|k|v, norm3 -> GEGLU run folded
+    x = torch.randn(B, Ci, H, H, device="cuda")
+    x2 = torch.randn(B, Ci2, H, H, device="cuda") if Ci2 else None
+    w = torch.randn(Co, ct, k, k, device="cuda") / (ct * k * k) ** 0.5
+    b = torch.randn(Co, device="cuda")
+    Hl = 2 * H if up else H
+    Ho = (Hl - 1) // 2 + 1 if (k == 3 and stride == 2) else Hl
+    cout = Co // 2 if geglu else Co
+    res = torch.randn(B, cout, Ho, Ho, device="cuda") if use_res else None
+    rb = torch.randn(B, Co, device="cuda") if (use_rb and not ln) else None
+    t = (x, x2, w, b, res, rb, (Ci, Ci2, H, Co, k, stride, up, geglu))
+    wbytes = Co * ct * k * k * (2 if DT else 4)
+    Lb.ldmseg_debug_set(6, max(1, min(24, (400 << 20) // wbytes)))
+    M, K = B * Ho * Ho, ct * k * k
+    nk = K // (64 if DT else 32)
+    fl = 2.0 * M * Co * K
+    h_us, h_name = bench(t, -1, 0, ln)
+    best = (h_us, -1, 0, h_name)
+    rows = []
+    for cfg in range(NCFG):
+        for sp in (1, 2, 3, 4, 6, 8, 12, 16):
+            if sp > 1 and (geglu or ln or nk // sp < 6):
+                continue
+            bm = 256 if cfg < 3 else (128 if cfg in (3, 4, 5, 8) else 64)
+            items = ((M + bm - 1) // bm) * (Co // (128 if geglu else 160 if Co % 160 == 0 else 128)) * sp
+            if sp > 1 and items > 1400:
+                continue
+            us, name = bench(t, cfg, sp, ln)
+            if us is None:
+                continue
+            rows.append((us, cfg, sp, name))
+            if us < best[0]:
+                best = (us, cfg, sp, name)
+    rows.sort()
+    print(f"M={M:6d} N={Co:5d} K={K:6d} k={k} s={stride} up={up} geglu={geglu} ln={int(ln)} res={use_res} rb={use_rb}: rules {h_us:7.1f} us "
+          f"({fl / h_us / 1e6:6.1f} TF) {h_name} | best {best[0]:7.1f} us ({fl / best[0] / 1e6:6.1f} TF) cfg={best[1]} splits={best[2]} {best[3]}")
+    print("      " + "  ".join(f"c{c}/s{s}:{u:.1f}" for u, c, s, _ in rows[:8]), flush=True)
+    tot_h += h_us
+    tot_b += best[0]
+    if best[1] >= 0 and best[0] < 0.97 * h_us:
+        table.append((DT, M, Co, K, k * k, stride, up, 1 if geglu else 0, int(ln), best[1], best[2], h_us, best[0]))
+print(f"sum over distinct shapes: rules {tot_h:.1f} us, best {tot_b:.1f} us")
+os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+out = os.path.join(ROOT, "gpurun_out", f"tuned_B{B}_L{LAT}_{DTN}.inc")
+seen = set()
+with open(out, "w") as f:
+    f.write(f"    // B={B}, {LAT}x{LAT} latents, {DTN} (tools/tune_igemm.py): dtype, M, N, K, taps, stride, up, epi, lnf, entry, K slices\n")
+    for e in table:
+        if e[:9] in seen:
+            continue                  # the same launch shape with / without residual or time-embedding row: first one wins
+        seen.add(e[:9])
+        f.write("    {" + ", ".join(str(v) for v in e[:11]) + "},   // " + f"{e[11]:.1f} -> {e[12]:.1f} us\n")
+print("wrote", out)
