@@ -158,6 +158,32 @@ __device__ __forceinline__ float gelu_erf_f(float x) {
   return 0.5f * x * (1.0f + copysignf(erf_abs, x));
 }
 
+// erf-GELU for results that are rounded to bf16 anyway: erf(x / sqrt 2) ~ x * R(x^2) on |x| <= 3 sqrt 2 (degree-8 weighted
+// least-squares fit in x^2, saturated beyond), |gelu error| <= 5e-5 absolute, < 6e-6 relative for large |x| - two orders
+// below a bf16 ulp of the output.  No v_rcp / v_exp (quarter rate) and the Horner chain runs as v_pk_fma_f32 on pairs: about
+// 8 VALU slots per element against ~23 for gelu_erf_f.  The GEGLU epilogue of the 64x64 maps is VALU-bound on exactly this
+// (32 activations per lane per item against five K tiles of MFMA).
+__device__ __forceinline__ f32x4 gelu_erf_bf16_f4(f32x4 x) {
+  const float XC = 4.2426405f;
+  f32x4 xc;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) xc[r] = __builtin_amdgcn_fmed3f(x[r], -XC, XC);
+  const f32x4 u = xc * xc;
+  f32x4 q = u * 8.812844898e-11f + -8.762744308e-09f;
+  q = q * u + 3.867438352e-07f;
+  q = q * u + -1.007556784e-05f;
+  q = q * u + 1.743170724e-04f;
+  q = q * u + -2.139258897e-03f;
+  q = q * u + 1.936233975e-02f;
+  q = q * u + -1.322318017e-01f;
+  q = q * u + 7.975320816e-01f;
+  f32x4 e = xc * q;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_fmed3f(e[r], -1.0f, 1.0f);
+  const f32x4 h = x * 0.5f;
+  return h * e + h;
+}
+
 // One MFMA "k-group" = 64 bytes of K per operand row (4 lane-groups x 16 B):
 // bf16: one v_mfma_f32_16x16x32_bf16; f32: four v_mfma_f32_16x16x4_f32, lane
 // group g supplying k = 4*g + t in the t-th instruction (any K permutation is

@@ -331,20 +331,57 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LDR) * 64, (WAVES_M * WAVES_N 
 #pragma unroll
       for (int a = 0; a < NF; ++a) c1v[a] = *(const f32x4*)(p.c1 + nl + a * 16);
     }
+    // Everything a 16-row block needs from global memory is requested one block ahead (the first block's requests
+    // go out here, before any staging): residual chunks, LayerNorm row statistics.  Issued at their point of use they
+    // cost one exposed L2 / HBM round trip per block, MF times per item, in a tail nothing else overlaps.
+    constexpr int NI = (NCH + 63) / 64;
+    const int m_wave = m0 + wm * WTM;
+    const bool has_res = p.resid != nullptr && !DBG(p, 128);
+    auto load_res = [&](int b, uint4 (&r)[NI]) __attribute__((always_inline)) {
+      if (!has_res) return;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int c = lane + i * 64;
+        const int row = c / CPR, cc = c - row * CPR;
+        const int m = m_wave + b * 16 + row, n = n0 + wn * WTN + cc * E;
+        if (c < NCH && m < p.M && n < p.n_valid) r[i] = *(const uint4*)((const T*)p.resid + (size_t)m * p.ldr + n);
+      }
+    };
+    auto load_st = [&](int b) __attribute__((always_inline)) -> float2 {
+      const int m = m_wave + b * 16 + lq;
+      return *(const float2*)(p.rowstats + (size_t)(m < p.M ? m : p.M - 1) * 2);
+    };
+    uint4 rcur[NI], rnext[NI];
+    float2 st_cur = make_float2(0.f, 1.f), st_next = st_cur;
+    load_res(0, rcur);
+    if constexpr (LNF) st_cur = load_st(0);
+    // time-embedding row: one image per tile (every map of 16x16 and up) -> it is the same for all rows, add it to the bias
+    // quads once; tiles that span images (8x8 maps) fetch it per block
+    bool rb_rows = false;
+    if (!LNF && p.rowbias) {
+      const int m_last = (m0 + BM <= p.M ? m0 + BM : p.M) - 1;
+      const int img0 = m0 / HWo;
+      if (img0 == m_last / HWo) {
+        const float* rbp = p.rowbias + (size_t)img0 * p.rb_stride + nl;
+#pragma unroll
+        for (int a = 0; a < NF; ++a) bv[a] += *(const f32x4*)(rbp + a * 16);
+      } else {
+        rb_rows = true;
+      }
+    }
     // One 16-row block of the wave's tile.  BI = accumulator slot that holds it.
     auto row_block = [&](int b, auto bidx) __attribute__((always_inline)) {
       constexpr int BI = decltype(bidx)::value;
-      const int mb = m0 + wm * WTM + b * 16;
+      const int mb = m_wave + b * 16;
       STAMP(p, 6 + 2 * b)
       {
-        const int m = mb + lq;
-        const int bimg = (m < p.M ? m : p.M - 1) / HWo;
         if constexpr (LNF) {                               // folded LayerNorm: rstd * (acc - mean * c1) + c2
-          const float2 st = *(const float2*)(p.rowstats + (size_t)(m < p.M ? m : p.M - 1) * 2);
 #pragma unroll
           for (int a = 0; a < NF; ++a)
-            *(f32x4*)(stg + lq * SROW + (a * 16 + lg * 4) * 4) = (acc[a][BI] - c1v[a] * st.x) * st.y + bv[a];
-        } else if (p.rowbias) {                                   // time-embedding row of this pixel's image
+            *(f32x4*)(stg + lq * SROW + (a * 16 + lg * 4) * 4) = (acc[a][BI] - c1v[a] * st_cur.x) * st_cur.y + bv[a];
+        } else if (rb_rows) {                              // time-embedding row of this pixel's image
+          const int m = mb + lq;
+          const int bimg = (m < p.M ? m : p.M - 1) / HWo;
           const float* rbp = p.rowbias + (size_t)bimg * p.rb_stride + nl;
           f32x4 rb[NF];
 #pragma unroll
@@ -358,10 +395,16 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LDR) * 64, (WAVES_M * WAVES_N 
             *(f32x4*)(stg + lq * SROW + (a * 16 + lg * 4) * 4) = acc[a][BI] + bv[a];
         }
       }
+      // (requested after the staging writes: this block's accumulators are dead by now, which is what makes room for them
+      // in the 168-register budget of the 12-wave tiles)
+      if (b + 1 < MF) {
+        load_res(b + 1, rnext);
+        if constexpr (LNF) st_next = load_st(b + 1);
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's block is in LDS (per-wave region)
       STAMP(p, 7 + 2 * b)
 #pragma unroll
-      for (int i = 0; i < (NCH + 63) / 64; ++i) {
+      for (int i = 0; i < NI; ++i) {
         const int c = lane + i * 64;
         if (c < NCH) {
           const int row = c / CPR, cc = c - row * CPR;
@@ -375,9 +418,9 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LDR) * 64, (WAVES_M * WAVES_N 
               const f32x4 t = *(const f32x4*)(sp + q * 16);
               v[q * 4 + 0] = t[0]; v[q * 4 + 1] = t[1]; v[q * 4 + 2] = t[2]; v[q * 4 + 3] = t[3];
             }
-            if (p.resid && !DBG(p, 128)) {
+            if (has_res) {
               float r[E];
-              Chunk<T>::unpack(*(const uint4*)((const T*)p.resid + (size_t)m * p.ldr + n), r);
+              Chunk<T>::unpack(rcur[i], r);
 #pragma unroll
               for (int e = 0; e < E; ++e) v[e] += r[e];
             }
@@ -391,6 +434,9 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LDR) * 64, (WAVES_M * WAVES_N 
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next block overwrites
+#pragma unroll
+      for (int i = 0; i < NI; ++i) rcur[i] = rnext[i];
+      st_cur = st_next;
     };
     // Two-block tiles keep the loop ROLLED (the current block is always slot 0, the other rotates down):
     // measured -5..10 % on the 128-row conv launches, whose single item per workgroup runs this code cold.
@@ -435,11 +481,17 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LDR) * 64, (WAVES_M * WAVES_N 
         for (int a = 0; a < NF; ++a) c1v[a] = *(const f32x4*)(p.c1 + nl + a * 16);
       }
       const int oc0 = (n0 + wn * WTN) >> 1;
+      // folded LayerNorm: rstd * (acc - mean * c1) + c2; the row statistics of a block are requested one block ahead
+      auto load_st = [&](int b) __attribute__((always_inline)) -> float2 {
+        const int m = m0 + wm * WTM + b * 16 + lq;
+        return *(const float2*)(p.rowstats + (size_t)(m < p.M ? m : p.M - 1) * 2);
+      };
+      float2 st = make_float2(0.f, 1.f), st_next = st;
+      if constexpr (LNF) st = load_st(0);
       auto row_block = [&](int b, auto bidx) __attribute__((always_inline)) {
         constexpr int BI = decltype(bidx)::value;
         const int mb = m0 + wm * WTM + b * 16;
-        float2 st = make_float2(0.f, 1.f);                 // folded LayerNorm: rstd * (acc - mean * c1) + c2
-        if constexpr (LNF) st = *(const float2*)(p.rowstats + (size_t)(mb + lq < p.M ? mb + lq : p.M - 1) * 2);
+        if constexpr (LNF) { if (b + 1 < MF) st_next = load_st(b + 1); }
 #pragma unroll
         for (int a = 0; a < NF; a += 2) {
           f32x4 av = acc[a][BI], gv = acc[a + 1][BI];
@@ -450,8 +502,12 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LDR) * 64, (WAVES_M * WAVES_N 
           av += bv[a];
           gv += bv[a + 1];
           f32x4 o;
+          if constexpr (sizeof(T) == 2) {
+            o = DBG(p, 128) ? av * gv : av * gelu_erf_bf16_f4(gv);
+          } else {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = av[r] * gelu_erf_f(gv[r]);
+            for (int r = 0; r < 4; ++r) o[r] = av[r] * gelu_erf_f(gv[r]);
+          }
           *(f32x4*)(stg + lq * SROW + ((a >> 1) * 16 + lg * 4) * 4) = o;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -469,11 +525,13 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LDR) * 64, (WAVES_M * WAVES_N 
                 const f32x4 t = *(const f32x4*)(sp + q * 16);
                 v[q * 4 + 0] = t[0]; v[q * 4 + 1] = t[1]; v[q * 4 + 2] = t[2]; v[q * 4 + 3] = t[3];
               }
-              *(uint4*)((T*)p.out + (size_t)m * p.ldo + oc0 + cc * E) = Chunk<T>::pack(v);
+              if (!DBG(p, 64)) *(uint4*)((T*)p.out + (size_t)m * p.ldo + oc0 + cc * E) = Chunk<T>::pack(v);
+              else asm volatile("" ::"v"(v[0]), "v"(v[E - 1]));
             }
           }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        st = st_next;
       };
       static_for<MF>([&](auto bi) __attribute__((always_inline)) { row_block(decltype(bi)::value, bi); });
     }
