@@ -156,7 +156,7 @@ def csrc_hash():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "latent-diffusion-segmentation_amd", "csrc")
     for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".h")):
+        if name.endswith((".hip", ".h", ".inc")):
             with open(os.path.join(d, name), "rb") as fh:
                 h.update(name.encode())
                 h.update(fh.read())

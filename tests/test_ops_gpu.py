@@ -113,6 +113,52 @@ def test_linear(L, dt, case):
 
 
 @pytest.mark.parametrize("dt", [F32, BF16])
+def test_geglu_gate_range(L, dt):
+    """GEGLU with gates spread over [-12, 12]: the bf16 epilogue evaluates erf by a polynomial on |x| <= 3*sqrt(2) and
+    saturates beyond (common.h gelu_erf_bf16_f4, |error| <= 5e-5 absolute); the fp32 one keeps Abramowitz-Stegun 7.1.26
+    (1.5e-7).  An identity weight makes value and gate columns exactly the (storage-rounded) inputs."""
+    M, K, N = 512, 256, 256                              # (GEGLU launches take N in multiples of 128 GEMM columns)
+    g = torch.Generator().manual_seed(5)
+    gate = torch.linspace(-12.0, 12.0, M * 128).reshape(M, 128)[torch.randperm(M, generator=g)]
+    val = torch.randn(M, 128, generator=g)
+    x = torch.cat([val, gate], 1)                       # ff.net.0.proj rows are [value | gate]
+    w = torch.eye(N, K)
+    b = torch.zeros(N)
+    xr = bf16_round(x) if dt == BF16 else x
+    a, gt = xr.chunk(2, -1)
+    ref = a * F.gelu(gt)
+    out = torch.empty(M, N // 2, device="cuda")
+    assert L.lib().ldmseg_op_linear(P(dev(x)), P(dev(w)), P(dev(b)), None, None, M, M, K, N, 1, 0, 1, dt, P(out), None) == 0
+    torch.cuda.synchronize()
+    err = (out.cpu() - ref).abs()
+    if dt == BF16:
+        # output rounding to bf16 (2^-9 relative) + the 5e-5 absolute bound of the polynomial (scaled by |value|)
+        assert bool((err <= ref.abs() * 2.0 ** -8 + 1e-4 * (1 + a.abs())).all()), float(err.max())
+    else:
+        assert float(err.max()) < 2e-5 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("case", [
+    # B, C, HW: the two-launch scheme, the single-launch register-resident kernel, the small-map kernel
+    (2, 320, 4096), (8, 1280, 256), (8, 1280, 16),
+])
+def test_groupnorm_large_mean(L, case):
+    """Channel means 1000x the standard deviation (fp32 mode): E[x^2] - E[x]^2 in fp32 would lose the variance entirely
+    (1e6 against 1 at 6e-8 relative precision); the kernels combine (count, mean, M2) triples instead (norm.hip chan_add)."""
+    B, Cc, HW = case
+    g = torch.Generator().manual_seed(HW)
+    x = (torch.randn(B, Cc, HW, generator=g, dtype=torch.float64) + 1000.0).float()
+    gamma = 1 + 0.1 * torch.randn(Cc, generator=g)
+    beta = 0.1 * torch.randn(Cc, generator=g)
+    ref = F.group_norm(x.double(), 32, gamma.double(), beta.double(), 1e-5).float()
+    out = torch.empty(B, Cc, HW, device="cuda")
+    assert L.lib().ldmseg_op_groupnorm(P(dev(x)), None, P(dev(gamma)), P(dev(beta)), B, Cc, 0, HW, 1e-5, 0, F32, P(out), None) == 0
+    torch.cuda.synchronize()
+    # the inputs themselves carry 1000 * 6e-8 = 6e-5 of rounding relative to a unit deviation
+    assert rel_err(out, ref) < 1e-3, case
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
 @pytest.mark.parametrize("case", [
     # B, C, C2, HW, eps, silu
     (2, 320, 0, 256, 1e-5, 1),

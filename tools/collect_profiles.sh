@@ -1,16 +1,24 @@
 #!/bin/bash
-# run on the GPU box from the repo root; writes everything under gpurun_out/prof_final
+# Run on the GPU box from the repo root (gpurun): every measurement profiles/ holds for one round, from ONE box.
+#   bash tools/collect_profiles.sh r02     -> gpurun_out/prof_r02/...;  then locally: python tools/import_profiles.py r02
 set -x
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_final; mkdir -p $O
+TAG=${1:-r02}
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_$TAG; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
-BENCH="python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-images --profile-steps 0"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o r1 -- $BENCH > $O/bench_under_rocprof.json 2> $O/stats.err
-BENCH3="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-images --profile-steps 0"
+BENCH="python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-images --no-extras --profile-steps 0"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- $BENCH > $O/bench_under_rocprof.json 2> $O/stats.err
+BENCH3="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-images --no-extras --profile-steps 0"
 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -- $BENCH3 > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -- $BENCH3 > $O/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE -d $O/pmc_mfma -- $BENCH3 > $O/pmc_mfma.log 2>&1
-for d in pmc_fetch pmc_write pmc_mfma; do python $R/tools/pmc_query.py $O/$d igemm_kernel > $O/$d.txt 2>&1; python $R/tools/pmc_query.py $O/$d attention_kernel >> $O/$d.txt 2>&1; done
-cd $R; python tools/prof_layers.py bf16 8 > $O/layers_top.txt 2>&1; cp gpurun_out/layers.csv $O/per_launch_events.csv
-python bench.py > $O/bench.json 2> $O/bench.err
-find $O -name "*.db" -size +20M -delete
+for d in pmc_fetch pmc_write pmc_mfma; do
+  python $R/tools/pmc_query.py $O/$d igemm_kernel > $O/$d.txt 2>&1
+  python $R/tools/pmc_query.py $O/$d attn3_kernel >> $O/$d.txt 2>&1
+done
+cd $R
+bash tools/trace_layers.sh bf16 8; cp gpurun_out/trace_layers.txt $O/trace_layers_b8_l64_bf16.txt; cp gpurun_out/layers.csv $O/per_launch_events.csv
+python bench.py > $O/bench_default.json 2> $O/bench_default.err
+for u in mfma_lds buf_lds valu_trans; do [ -x tools/ubench/bin/$u ] && timeout 300 tools/ubench/bin/$u > $O/ubench_$u.txt 2>&1; done
+python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; tail -2 $O/pytest_gpu.log
+find $O -name "*.db" -delete; find $O -name "*kernel_trace.csv" -size +8M -delete
 du -sh $O

@@ -1,0 +1,64 @@
+#!/usr/bin/env python
+"""Copy the summaries of gpurun_out/prof_<tag>/ (tools/collect_profiles.sh) into profiles/<tag>_* and derive
+<tag>_pmc_traffic.json (HBM bytes per igemm launch, the figure bench.py reports as roofline.traffic)."""
+import glob, json, os, re, shutil, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+src, dst = os.path.join(ROOT, "gpurun_out", f"prof_{tag}"), os.path.join(ROOT, "profiles")
+
+
+def cp(a, b):
+    a = os.path.join(src, a)
+    if os.path.exists(a):
+        shutil.copy(a, os.path.join(dst, f"{tag}_{b}"))
+        print("->", f"{tag}_{b}")
+
+
+for f in glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True):
+    shutil.copy(f, os.path.join(dst, f"{tag}_kernel_stats_bench_b8_l64_bf16.csv"))
+for f in glob.glob(os.path.join(src, "stats", "**", "*agent_info.csv"), recursive=True):
+    shutil.copy(f, os.path.join(dst, f"{tag}_agent_info.csv"))
+cp("bench_under_rocprof.json", "bench_under_rocprof.json")
+cp("bench_default.json", "bench_default.json")
+cp("per_launch_events.csv", "per_launch_events_unet_forward_b8_l64_bf16.csv")
+cp("trace_layers_b8_l64_bf16.txt", "kernel_trace_per_layer_b8_l64_bf16.txt")
+for n in ("pmc_fetch", "pmc_write", "pmc_mfma"):
+    cp(n + ".txt", n + ".txt")
+for u in ("mfma_lds", "buf_lds", "valu_trans"):
+    cp(f"ubench_{u}.txt", f"ubench_{u}.txt")
+cp("pytest_gpu.log", "pytest_gpu.log")
+
+
+def per_dispatch(path, counter, kernel):
+    """sum over instantiations of (dispatches x per-dispatch total) for `counter` on kernels whose name contains `kernel`"""
+    names, vals, tot_n, tot_v = [], [], 0, 0.0
+    for ln in open(path):
+        m = re.match(r"dispatches (\S+) (\d+) avg_ns", ln)
+        if m:
+            names.append((m.group(1), int(m.group(2))))
+        m = re.match(rf"{counter}\s+per-dispatch total\s+([\d.]+)", ln)
+        if m:
+            vals.append(float(m.group(1)))
+    ig = [(n, c) for n, c in names if kernel in n]
+    for (n, c), v in zip(ig, vals[:len(ig)]):
+        tot_n += c
+        tot_v += c * v
+    return tot_n, tot_v
+
+
+try:
+    n_f, kib_f = per_dispatch(os.path.join(dst, f"{tag}_pmc_fetch.txt"), "FETCH_SIZE", "igemm_kernel")
+    n_w, kib_w = per_dispatch(os.path.join(dst, f"{tag}_pmc_write.txt"), "WRITE_SIZE", "igemm_kernel")
+    import bench
+    out = {"kernel": "igemm_kernel (all instantiations)", "launches": n_f, "forwards": n_f // 162,
+           "fetch_bytes_per_launch": 2 * 1024 * kib_f / n_f, "write_bytes_per_launch": 1024 * kib_w / n_w,
+           "hbm_bytes_per_launch": 2 * 1024 * kib_f / n_f + 1024 * kib_w / n_w, "csrc_sha": bench.csrc_hash(),
+           "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 3 --warmup 1 "
+                     "--no-cpu-baseline --no-images --no-extras --profile-steps 0`; FETCH_SIZE (KiB) doubled per MI355X_MICROARCH.md "
+                     "(HBM section: gfx950 tallies 128-B requests at 64 B); WRITE_SIZE uncalibrated; Infinity-Cache hits are counted",
+           "source": [f"profiles/{tag}_pmc_fetch.txt", f"profiles/{tag}_pmc_write.txt"]}
+    json.dump(out, open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
+    print(json.dumps(out, indent=1))
+except Exception as e:  # noqa: BLE001
+    print("pmc_traffic not derived:", e)
