@@ -17,6 +17,12 @@
 namespace ldmseg {
 namespace {
 
+#ifdef LDMSEG_GN_STAMP
+__device__ unsigned long long g_gn_ts[8192 * 8];
+#define GNSTAMP(slot) if (threadIdx.x == 0) g_gn_ts[((size_t)blockIdx.y * gridDim.x + blockIdx.x) % 8192 * 8 + (slot)] = __builtin_amdgcn_s_memtime();
+#else
+#define GNSTAMP(slot)
+#endif
 constexpr int kMaxIter = 4;   // ceil(nvec / 256) supported (C*sizeof(T)/16 <= 1024)
 
 template <typename T>
@@ -40,35 +46,54 @@ __device__ __forceinline__ void chan_add(double& n, double& mean, double& m2, do
 }
 
 // fixed-order reduction of one image's per-chunk partials {mean, M2}: 8 lanes per group (each a fixed chunk subset,
-// fixed shuffle tree -> deterministic), fp64.  256 threads; out = {mean, rstd} per group.
+// fixed shuffle tree -> deterministic).  256 threads; out = {mean, rstd} per group.
+// Closed form of the pairwise update, in two passes over the register-resident partials: with delta_i = mean_i - K
+// (K = the group's first chunk mean, so the deltas are of the order of the deviation and fp32 carries them exactly
+// enough even under a channel mean 1000x larger),  mean = K + sum n_i delta_i / N,  M2 = sum M2_i + n_i (delta_i - dbar)^2.
+// All loads are issued before the first use.  The earlier form - a rolled loop of one dependent L2 load + one fp64
+// pairwise update (two fp64 divisions) per chunk - cost 5.6 us in front of every apply workgroup's first pixel and
+// 3.8 us at the end of every statistics workgroup (s_memtime stamps, tools/gn_stamps.py), as much as the streaming itself.
+__device__ __forceinline__ float sum8_fixed(float v) {
+#pragma unroll
+  for (int o = 4; o > 0; o >>= 1) {
+    const float w = __shfl_xor(v, o);
+    v = (threadIdx.x & o) ? w + v : v + w;      // same operand order on both partners
+  }
+  return v;
+}
 __device__ __forceinline__ void gn_reduce_stats(const GNParams& p, int b, int cpg, float* out) {
   const int g = threadIdx.x >> 3, sub = threadIdx.x & 7;
   const int per = (p.HW + p.nchunk - 1) / p.nchunk;
-  double n = 0.0, mean = 0.0, m2 = 0.0;
-  if (g < p.groups) {
-    for (int ch = sub; ch < p.nchunk; ch += 8) {
-      const int p0 = ch * per, p1 = min(p.HW, p0 + per);
-      if (p1 <= p0) continue;
-      const float2 pp = *(const float2*)(p.partial + (((size_t)b * p.nchunk + ch) * p.groups + g) * 2);
-      chan_add(n, mean, m2, (double)(p1 - p0) * cpg, (double)pp.x, (double)pp.y);
-    }
-  }
+  constexpr int MAXP = 16;                     // nchunk <= 128 (gn_nchunk)
+  float2 pp[MAXP];
+  float cnt[MAXP];                             // exact: pixels x channels per group < 2^24
+  const float2* src = (const float2*)p.partial + ((size_t)b * p.nchunk * p.groups + (g < p.groups ? g : 0));
 #pragma unroll
-  for (int o = 4; o > 0; o >>= 1) {
-    const double nb = __shfl_xor(n, o), mb = __shfl_xor(mean, o), m2b = __shfl_xor(m2, o);
-    // both partners must end up with the same value: combine in a lane-independent order (lower lane first)
-    if (threadIdx.x & o) {
-      double n2 = nb, mean2 = mb, m22 = m2b;
-      chan_add(n2, mean2, m22, n, mean, m2);
-      n = n2; mean = mean2; m2 = m22;
-    } else {
-      chan_add(n, mean, m2, nb, mb, m2b);
-    }
+  for (int i = 0; i < MAXP; ++i) {
+    const int ch = sub + i * 8;
+    const int p0 = ch * per, p1 = min(p.HW, p0 + per);
+    const bool ok = g < p.groups && ch < p.nchunk && p1 > p0;
+    pp[i] = src[(size_t)(ok ? ch : 0) * p.groups];
+    cnt[i] = ok ? (float)((p1 - p0) * cpg) : 0.f;
   }
+  const float K = __shfl(pp[0].x, threadIdx.x & ~7);          // chunk 0 of this group (always populated)
+  float n = 0.f, sd = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i) { n += cnt[i]; sd += cnt[i] * (pp[i].x - K); }
+  n = sum8_fixed(n);
+  sd = sum8_fixed(sd);
+  const float dbar = n > 0.f ? sd / n : 0.f;
+  float m2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXP; ++i) {
+    const float d = (pp[i].x - K) - dbar;
+    m2 += cnt[i] > 0.f ? pp[i].y + cnt[i] * d * d : 0.f;
+  }
+  m2 = sum8_fixed(m2);
   if (g < p.groups && sub == 0) {
-    const double var = n > 0.0 ? m2 / n : 0.0;
-    out[g * 2 + 0] = (float)mean;
-    out[g * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.eps));
+    const float var = n > 0.f ? m2 / n : 0.f;
+    out[g * 2 + 0] = K + dbar;
+    out[g * 2 + 1] = 1.0f / sqrtf(var + p.eps);
   }
 }
 
@@ -88,6 +113,7 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const GNParams p) {
   const int p1 = min(p.HW, p0 + per);
 
   __shared__ float red[kMaxIter][256][4];   // per thread: {mean, M2} of its low / high group part
+  GNSTAMP(0)
 
   const int niter = (nvec + VX - 1) / VX;
   for (int it = 0; it < niter; ++it) {
@@ -142,35 +168,62 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const GNParams p) {
     red[it][tid][0] = k0 + ms0; red[it][tid][1] = fmaxf(q0 - s0 * ms0, 0.f);
     red[it][tid][2] = k1 + ms1; red[it][tid][3] = fmaxf(q1 - s1 * ms1, 0.f);
   }
+  GNSTAMP(1)
   __syncthreads();
-  // fixed-order combination: thread g -> group g
-  if (tid < p.groups) {
-    const int g = tid;
-    const int c_lo = g * cpg, c_hi = c_lo + cpg - 1;
-    // vectors overlapping channels [c_lo, c_hi]: low part feeds g when g0==g, high part when g0+1==g
-    const int v_first = max(0, c_lo / PC - 1);
-    const int v_last = min(nvec - 1, c_hi / PC);
-    double n = 0.0, mean = 0.0, m2 = 0.0;
-    for (int v = v_first; v <= v_last; ++v) {
+  GNSTAMP(2)
+  // fixed-order combination, 8 lanes per group (lane `sub` takes the thread rows y = sub, sub+8, ...), no integer division
+  // in the loops (a runtime divide is a ~40-instruction sequence: the one-thread-per-group form of this block, with three
+  // of them per pair, took 3.8 us - as long as the loads).  Deltas against one pair's mean as in gn_reduce_stats.
+  {
+    const int g = tid >> 3, sub = tid & 7;
+    const bool gv = g < p.groups;
+    const int c_lo = (gv ? g : 0) * cpg;
+    const int v_first = max(0, c_lo / PC - 1);                    // (PC is a compile-time power of two)
+    const int v_last = min(nvec - 1, (c_lo + cpg - 1) / PC);
+    const int npx = p1 - p0;
+    const int np_base = npx / TY, np_rem = npx - np_base * TY;    // thread row y holds np_base + (y < np_rem) pixels
+    auto locate = [&](int v, int& it, int& x, int& part, int& cnt) __attribute__((always_inline)) {
       const int c0 = v * PC;
-      const int g0 = c0 / cpg;
-      const int split = min(PC, (g0 + 1) * cpg - c0);
-      const int it = v / VX, x = v - it * VX;
-      int part, cnt;
-      if (g0 == g) { part = 0; cnt = split; }
-      else if (g0 + 1 == g) { part = 2; cnt = PC - split; }
-      else continue;
-      if (cnt == 0) continue;
-      for (int y = 0; y < TY; ++y) {
-        const int first = p0 + y;
-        const int np = first < p1 ? (p1 - first + TY - 1) / TY : 0;
-        chan_add(n, mean, m2, (double)np * cnt, (double)red[it][y * VX + x][part], (double)red[it][y * VX + x][part + 1]);
+      it = 0; x = v;
+      while (x >= VX) { x -= VX; ++it; }
+      if (c0 >= c_lo && c0 < c_lo + cpg) { part = 0; cnt = min(PC, c_lo + cpg - c0); }
+      else if (c0 < c_lo && c0 + PC > c_lo) { part = 2; cnt = c0 + PC - c_lo; }
+      else { part = 0; cnt = 0; }
+    };
+    float K;
+    {
+      int it, x, part, cnt;
+      locate(c_lo / PC, it, x, part, cnt);                         // the vector that holds channel c_lo, thread row 0
+      K = red[it][x][part];
+    }
+    float n = 0.f, sd = 0.f, m2 = 0.f;
+    for (int pass = 0; pass < 2; ++pass) {
+      float dbar = 0.f;
+      if (pass) { n = sum8_fixed(n); sd = sum8_fixed(sd); dbar = n > 0.f ? sd / n : 0.f; }
+      for (int v = v_first; v <= v_last; ++v) {
+        int it, x, part, cnt;
+        locate(v, it, x, part, cnt);
+        if (cnt == 0) continue;
+        for (int y = sub; y < TY; y += 8) {
+          const int np = np_base + (y < np_rem ? 1 : 0);
+          if (np == 0) continue;
+          const float2 e = *(const float2*)&red[it][y * VX + x][part];
+          const float c = (float)(np * cnt);
+          if (!pass) { n += c; sd += c * (e.x - K); }
+          else { const float d = (e.x - K) - dbar; m2 += e.y + c * d * d; }
+        }
+      }
+      if (pass) {
+        m2 = sum8_fixed(m2);
+        if (gv && sub == 0) {
+          float* dst = p.partial + (((size_t)b * p.nchunk + chunk) * p.groups + g) * 2;
+          dst[0] = K + dbar;
+          dst[1] = m2;
+        }
       }
     }
-    float* dst = p.partial + (((size_t)b * p.nchunk + chunk) * p.groups + g) * 2;
-    dst[0] = (float)mean;
-    dst[1] = (float)m2;
   }
+  GNSTAMP(3)
 }
 
 template <typename T>
@@ -181,58 +234,72 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GNParams p) {
   const int nvec = C / PC;
   const int b = blockIdx.y;
   __shared__ float s_stat[64][2];
-  // every apply workgroup reduces the image's partials itself.  (Having the last-finishing partial workgroup finalise
-  // (mean, rstd) behind a ticket needs agent-scope fences, which on this 8-XCD part write back / invalidate whole
-  // L2s: measured 2.4x slower for the GroupNorm family.)
-  gn_reduce_stats(p, b, cpg, &s_stat[0][0]);
-  __syncthreads();
+  GNSTAMP(4)
   // every thread owns fixed channel vectors, so the per-channel affine (x*a + b with
   // a = rstd*gamma, b = beta - mean*a) is computed once and the pixel loop is one FMA per element
   const int VX = nvec < 256 ? nvec : 256;
   const int TY = 256 / VX;
   const int tid = threadIdx.x;
   const int tx = tid % VX, ty = tid / VX;
-  if (ty >= TY) return;
+  const bool act = ty < TY;
   const int per = (p.HW + gridDim.x - 1) / gridDim.x;
   const int p0 = blockIdx.x * per;
   const int p1 = min(p.HW, p0 + per);
-  for (int v = tx; v < nvec; v += VX) {
+  const T* src = nullptr;
+  T* dst = nullptr;
+  int cs = 0;
+  auto locate = [&](int v) __attribute__((always_inline)) {
     const int c0 = v * PC;
-    float a[PC], bb[PC];
-#pragma unroll
-    for (int e = 0; e < PC; ++e) {
-      const int c = c0 + e;
-      const int g = c / cpg;
-      a[e] = s_stat[g][1] * p.gamma[c];
-      bb[e] = p.beta[c] - s_stat[g][0] * a[e];
-    }
-    const T* src;
-    int cs, coff;
+    int coff;
     if (c0 < p.C0) { src = (const T*)p.src0; cs = p.C0; coff = c0; }
     else { src = (const T*)p.src1; cs = p.C1; coff = c0 - p.C0; }
     src += (size_t)b * p.HW * cs + coff;
-    T* dst = (T*)p.out + (size_t)b * p.HW * C + c0;
-    int pix = p0 + ty;
-    for (; pix + 3 * TY < p1; pix += 4 * TY) {          // four independent 16-B loads in flight per thread
-      uint4 raw[4];
+    dst = (T*)p.out + (size_t)b * p.HW * C + c0;
+  };
+  // Everything that does not depend on the statistics - the first four pixels of this thread's vector, its gamma / beta -
+  // is requested BEFORE the reduction of the partials, so that the reduction's own memory round trip and shuffle chain
+  // (about 4 us per workgroup by s_memtime stamps, as long as streaming the workgroup's ~11 pixels per thread) overlap
+  // with the first data round trip instead of preceding it.
+  uint4 raw0[4];
+  float gam[PC], bet[PC];
+  if (act) {
+    locate(tx);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) raw[u] = *(const uint4*)(src + (size_t)(pix + u * TY) * cs);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        float f[PC];
-        Chunk<T>::unpack(raw[u], f);
-#pragma unroll
-        for (int e = 0; e < PC; ++e) {
-          float y = f[e] * a[e] + bb[e];
-          if (p.silu) y = silu_f(y);
-          f[e] = y;
-        }
-        *(uint4*)(dst + (size_t)(pix + u * TY) * C) = Chunk<T>::pack(f);
-      }
+    for (int u = 0; u < 4; ++u) {
+      const int pix = p0 + ty + u * TY;
+      raw0[u] = pix < p1 ? *(const uint4*)(src + (size_t)pix * cs) : make_uint4(0, 0, 0, 0);
     }
-    for (; pix < p1; pix += TY) {
+#pragma unroll
+    for (int e = 0; e < PC; ++e) { gam[e] = p.gamma[tx * PC + e]; bet[e] = p.beta[tx * PC + e]; }
+  }
+  // every apply workgroup reduces the image's partials itself.  (Having the last-finishing partial workgroup finalise
+  // (mean, rstd) behind a ticket needs agent-scope fences, which on this 8-XCD part write back / invalidate whole
+  // L2s: measured 2.4x slower for the GroupNorm family.)
+  gn_reduce_stats(p, b, cpg, &s_stat[0][0]);
+  __syncthreads();
+  GNSTAMP(5)
+  if (!act) return;
+  for (int v = tx; v < nvec; v += VX) {
+    const int c0 = v * PC;
+    if (v != tx) {                                     // (only tensors with more than 256 vectors per pixel come here)
+      locate(v);
+#pragma unroll
+      for (int e = 0; e < PC; ++e) { gam[e] = p.gamma[c0 + e]; bet[e] = p.beta[c0 + e]; }
+    }
+    // a vector spans at most two groups (run_gn checks it): one runtime division per vector, not one per element
+    const int g0 = c0 / cpg;
+    const int split = min(PC, (g0 + 1) * cpg - c0);
+    const float m_lo = s_stat[g0][0], r_lo = s_stat[g0][1];
+    const float m_hi = s_stat[split < PC ? g0 + 1 : g0][0], r_hi = s_stat[split < PC ? g0 + 1 : g0][1];
+    float a[PC], bb[PC];
+#pragma unroll
+    for (int e = 0; e < PC; ++e) {
+      a[e] = (e < split ? r_lo : r_hi) * gam[e];
+      bb[e] = bet[e] - (e < split ? m_lo : m_hi) * a[e];
+    }
+    auto emit = [&](const uint4& raw, int pix) __attribute__((always_inline)) {
       float f[PC];
-      Chunk<T>::unpack(*(const uint4*)(src + (size_t)pix * cs), f);
+      Chunk<T>::unpack(raw, f);
 #pragma unroll
       for (int e = 0; e < PC; ++e) {
         float y = f[e] * a[e] + bb[e];
@@ -240,8 +307,24 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GNParams p) {
         f[e] = y;
       }
       *(uint4*)(dst + (size_t)pix * C) = Chunk<T>::pack(f);
+    };
+    int pix = p0 + ty;
+    if (v == tx) {                                     // the trip that was requested up front
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (pix + u * TY < p1) emit(raw0[u], pix + u * TY);
+      pix += 4 * TY;
     }
+    for (; pix + 3 * TY < p1; pix += 4 * TY) {          // four independent 16-B loads in flight per thread
+      uint4 raw[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) raw[u] = *(const uint4*)(src + (size_t)(pix + u * TY) * cs);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) emit(raw[u], pix + u * TY);
+    }
+    for (; pix < p1; pix += TY) emit(*(const uint4*)(src + (size_t)pix * cs), pix);
   }
+  GNSTAMP(6)
 }
 
 __device__ __forceinline__ float wave_sum(float v) { return wave64_sum(v); }
@@ -613,3 +696,9 @@ int launch_layernorm(const void* x, void* y, const float* gamma, const float* be
 }
 
 }  // namespace ldmseg
+
+#ifdef LDMSEG_GN_STAMP
+extern "C" int ldmseg_debug_gn_stamps(unsigned long long* host, int n) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(ldmseg::g_gn_ts), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
