@@ -33,6 +33,11 @@ typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 // NOTE: never apply __builtin_bit_cast directly to an ext_vector element (v[i]): hipcc 7.2 then
 // reads element 0.  Go through these by-value helpers instead.
+// n / d for 0 <= n < 2^31 with a divisor prepared by fastdiv_make() (kernels.h)
+template <typename FD>
+__device__ __forceinline__ int fd_div(int n, const FD& f) {
+  return f.mul ? (int)(__umulhi((unsigned)n, f.mul) >> f.shift) : n;
+}
 __device__ __forceinline__ uint32_t f32_bits(float f) { return __builtin_bit_cast(uint32_t, f); }
 __device__ __forceinline__ float bits_f32(uint32_t u) { return __builtin_bit_cast(float, u); }
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {

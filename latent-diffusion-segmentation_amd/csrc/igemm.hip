@@ -187,13 +187,13 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LDR) * 64, (WAVES_M * WAVES_N 
     woff[i] = (unsigned)(((size_t)((i * NLW + wave) * 8 + ld_r) * K) * sizeof(T)) + (unsigned)ld_j * 16u;
 
   auto item_range = [&](int item, int& m0, int& n0, int& z, int& kb, int& ke) __attribute__((always_inline)) {
-    const int tile = item % ntiles;
-    z = item / ntiles;
-    const int mt = tile / NT, nt = tile - mt * NT;
+    z = fd_div(item, p.fd_ntiles);                       // (all divisions here and in item_setup: see FastDiv, kernels.h)
+    const int tile = item - z * ntiles;
+    const int mt = fd_div(tile, p.fd_nt), nt = tile - mt * NT;
     m0 = mt * BM;
     n0 = nt * BN;
-    kb = (int)((long)nk_total * z / nsplit);
-    ke = (int)((long)nk_total * (z + 1) / nsplit);
+    kb = fd_div(nk_total * z, p.fd_nsplit);              // nk_total * splits < 2^31 (launch_igemm checks the shape)
+    ke = fd_div(nk_total * (z + 1), p.fd_nsplit);
   };
 
   // ================= fetch stream state (runs NST-1 K tiles ahead of the compute stream) =================
@@ -213,8 +213,8 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LDR) * 64, (WAVES_M * WAVES_N 
     for (int i = 0; i < XG; ++i) {
       const int m = m0 + (i * NLW + wave) * 8 + ld_r;
       if (m < p.M) {
-        const int b = m / HWo, rem = m - b * HWo;
-        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        const int b = fd_div(m, p.fd_hwo), rem = m - b * HWo;
+        const int oy = fd_div(rem, p.fd_wo), ox = rem - oy * p.Wo;
         ri[i].pix_base = b * p.Hi * p.Wi;
         ri[i].iy0 = oy * p.stride - pad;
         ri[i].ix0 = ox * p.stride - pad;
@@ -226,7 +226,7 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LDR) * 64, (WAVES_M * WAVES_N 
     }
     wtile0 = (const unsigned char*)p.W + (size_t)n0 * K * sizeof(T);
     const int tiles_per_tap = Ctot / BKE;
-    f_tap = f_kt / tiles_per_tap;
+    f_tap = fd_div(f_kt, p.fd_tpt);
     f_cc = (f_kt - f_tap * tiles_per_tap) * BKE;
     need_setup = true;
   };
@@ -360,8 +360,8 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LDR) * 64, (WAVES_M * WAVES_N 
     bool rb_rows = false;
     if (!LNF && p.rowbias) {
       const int m_last = (m0 + BM <= p.M ? m0 + BM : p.M) - 1;
-      const int img0 = m0 / HWo;
-      if (img0 == m_last / HWo) {
+      const int img0 = fd_div(m0, p.fd_hwo);
+      if (img0 == fd_div(m_last, p.fd_hwo)) {
         const float* rbp = p.rowbias + (size_t)img0 * p.rb_stride + nl;
 #pragma unroll
         for (int a = 0; a < NF; ++a) bv[a] += *(const f32x4*)(rbp + a * 16);
@@ -381,7 +381,7 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LDR) * 64, (WAVES_M * WAVES_N 
             *(f32x4*)(stg + lq * SROW + (a * 16 + lg * 4) * 4) = (acc[a][BI] - c1v[a] * st_cur.x) * st_cur.y + bv[a];
         } else if (rb_rows) {                              // time-embedding row of this pixel's image
           const int m = mb + lq;
-          const int bimg = (m < p.M ? m : p.M - 1) / HWo;
+          const int bimg = fd_div(m < p.M ? m : p.M - 1, p.fd_hwo);
           const float* rbp = p.rowbias + (size_t)bimg * p.rb_stride + nl;
           f32x4 rb[NF];
 #pragma unroll
@@ -548,7 +548,7 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LDR) * 64, (WAVES_M * WAVES_N 
   for (int b = 0; b < MF; ++b) {
     const int m = m0 + wm * WTM + b * 16 + (lane & 15);
     if (m >= p.M) continue;
-    const int bimg = m / HWo;
+    const int bimg = fd_div(m, p.fd_hwo);
     float2 st = make_float2(0.f, 1.f);                     // folded LayerNorm: rstd * (acc - mean * c1) + c2
     if constexpr (LNF) st = *(const float2*)(p.rowstats + (size_t)m * 2);
     if (p.epi == EPI_GEGLU) {
@@ -633,7 +633,7 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LDR) * 64, (WAVES_M * WAVES_N 
         const int tap = n / p.cout, co = n - tap * p.cout;
         const int dy = tap >> 1, dx = tap & 1;
         const int rem = m - bimg * HWo;
-        const int y = rem / p.Wo, x = rem - y * p.Wo;
+        const int y = fd_div(rem, p.fd_wo), x = rem - y * p.Wo;
         const size_t orow = ((size_t)bimg * 2 * p.Ho + 2 * y + dy) * (2 * p.Wo) + 2 * x + dx;
         T* o = (T*)p.out + orow * p.ldo + co;
         if constexpr (sizeof(T) == 2) {
@@ -831,15 +831,18 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LDR) * 64, (WAVES_M * WAVES_N 
 // split-K finish: out = sum_z partial[z] + bias (+rowbias)(+resid), optional SiLU  (EPI_STORE only)
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_finish_kernel(const IgemmParams p) {
+  // thread -> (row, channel quad) without a division: 64 quads x 4 rows per workgroup trip, rows strided over the grid
   const int nq = p.n_valid >> 2;
-  const size_t total = (size_t)p.M * nq;
-  const int HWo = p.Ho * p.Wo;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int m = (int)(i / nq), n = (int)(i - (size_t)m * nq) * 4;
+  const int q0 = blockIdx.x * 64 + (threadIdx.x & 63);
+  if (q0 >= nq) return;
+  const int n = q0 * 4;
+  f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (p.bias) bias = *(const f32x4*)(p.bias + n);
+  for (int m = blockIdx.y * 4 + (threadIdx.x >> 6); m < p.M; m += gridDim.y * 4) {
     f32x4 v = *(const f32x4*)(p.partial + (size_t)m * p.N + n);
     for (int z = 1; z < p.splits; ++z) v += *(const f32x4*)(p.partial + ((size_t)z * p.M + m) * p.N + n);
-    if (p.bias) v += *(const f32x4*)(p.bias + n);
-    if (p.rowbias) v += *(const f32x4*)(p.rowbias + (size_t)(m / HWo) * p.rb_stride + n);
+    v += bias;
+    if (p.rowbias) v += *(const f32x4*)(p.rowbias + (size_t)fd_div(m, p.fd_hwo) * p.rb_stride + n);
     if (p.resid) {
       const T* rp = (const T*)p.resid + (size_t)m * p.ldr + n;
       for (int r = 0; r < 4; ++r) v[r] += to_f32<T>(rp[r]);
@@ -926,6 +929,12 @@ int run(const IgemmParams& pin, hipStream_t s) {
   p.zeros = zero_page();
   if (!p.zeros) return -3;
   const int mt = (p.M + BM - 1) / BM, nt = p.N / BN;
+  p.fd_hwo = fastdiv_make(p.Ho * p.Wo);
+  p.fd_wo = fastdiv_make(p.Wo);
+  p.fd_nt = fastdiv_make(nt);
+  p.fd_ntiles = fastdiv_make(mt * nt);
+  p.fd_nsplit = fastdiv_make(p.splits > 1 ? p.splits : 1);
+  p.fd_tpt = fastdiv_make((p.C0 + p.C1) / (int)(kRowBytes / sizeof(T)));
   const int nwork = mt * nt * (p.splits > 1 ? p.splits : 1);
   // persistent grid: as many workgroups as fit on the chip at once (2 per CU for the 4-wave tiles,
   // 1 per CU for the 8-wave ones); each walks nwork / grid items
@@ -945,10 +954,11 @@ int run(const IgemmParams& pin, hipStream_t s) {
   if (g_log_on) g_log.insert(igemm_dispatch_name(g_last));
   hipLaunchKernelGGL(kern, dim3(grid_x), dim3((WM * WN + LDR) * 64), lds, s, p);
   if (p.splits > 1) {
-    const size_t total = (size_t)p.M * (p.n_valid >> 2);
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(splitk_finish_kernel<T>, dim3(blocks), dim3(256), 0, s, p);
+    const int nq = p.n_valid >> 2;
+    const int gx = (nq + 63) / 64;
+    int gy = (p.M + 3) / 4;
+    if (gy > 2048 / gx) gy = 2048 / gx > 0 ? 2048 / gx : 1;
+    hipLaunchKernelGGL(splitk_finish_kernel<T>, dim3(gx, gy), dim3(256), 0, s, p);
   }
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }

@@ -19,6 +19,27 @@ enum Epilogue : int {
   EPI_ROWS_F32 = 4,  // out is float row-major [M][ldo] whatever the compute dtype (attention scores of the image VAE)
 };
 
+// Exact n / d for 0 <= n < 2^31 by one v_mul_hi_u32 and a shift (Granlund-Montgomery: s = ceil(log2 d),
+// M = ceil(2^(31+s) / d) < 2^32, q = (n * M) >> (31 + s)).  A runtime integer division is a ~40-instruction VALU sequence
+// on this part; kernels whose first useful instruction sits behind several of them (row -> (image, y, x) of every gathered
+// row, item -> tile) pay microseconds per launch for it.  Divisors come from the host, made by fastdiv_make().
+struct FastDiv {
+  unsigned mul = 0;     // 0: divisor is 1
+  int shift = 0;        // applied to the high word
+  int d = 1;
+};
+inline FastDiv fastdiv_make(int d) {
+  FastDiv f;
+  f.d = d < 1 ? 1 : d;
+  if (f.d == 1) return f;
+  int s = 0;
+  while ((1ll << s) < f.d) ++s;
+  const unsigned long long num = 1ull << (31 + s);
+  f.mul = (unsigned)((num + (unsigned long long)f.d - 1) / (unsigned long long)f.d);
+  f.shift = s - 1;
+  return f;
+}
+
 struct IgemmParams {
   const void* src0 = nullptr;  // [B, Hi*Wi, C0]
   const void* src1 = nullptr;  // [B, Hi*Wi, C1]  channel-concat partner (torch.cat([h, skip],1))
@@ -53,6 +74,8 @@ struct IgemmParams {
   int splits = 1;
   float* partial = nullptr;
   const void* zeros = nullptr;   // >= 16 B of zeros (set by the launcher)
+  // set by the launcher: divisions the kernels need (by Ho*Wo, Wo, the number of n tiles / tiles / K slices, K tiles per tap)
+  FastDiv fd_hwo, fd_wo, fd_nt, fd_ntiles, fd_nsplit, fd_tpt;
   int dbg = 0;                   // ablation flags for profiling experiments (results are wrong when != 0)
   unsigned long long* ts = nullptr;   // LDMSEG_IGEMM_ABLATE builds: per-workgroup s_memtime stamps (wave 0)
 };
