@@ -108,6 +108,10 @@ struct GNParams {
   void* out = nullptr;         // [B, HW, C0+C1]
   float* partial = nullptr;    // workspace [B][nchunk][groups][2]
   int nchunk = 0;
+  // filled by launch_groupnorm (host): quantities the kernels would otherwise divide for before their first load
+  int cpg = 0, vx = 0, ty = 0, per = 0;                 // channels per group, threads per pixel row, pixel rows per trip, pixels per chunk
+  FastDiv fd_cpg, fd_vx, fd_aux;                        // aux: units / vectors per pixel of the small / fused kernels
+  double inv_n = 0.0;                                   // 1 / (HW * cpg)
 };
 int gn_nchunk(int B, int HW);
 int launch_groupnorm(const GNParams& p, int dtype, hipStream_t s);

@@ -63,7 +63,7 @@ __device__ __forceinline__ float sum8_fixed(float v) {
 }
 __device__ __forceinline__ void gn_reduce_stats(const GNParams& p, int b, int cpg, float* out) {
   const int g = threadIdx.x >> 3, sub = threadIdx.x & 7;
-  const int per = (p.HW + p.nchunk - 1) / p.nchunk;
+  const int per = p.per;
   constexpr int MAXP = 16;                     // nchunk <= 128 (gn_nchunk)
   float2 pp[MAXP];
   float cnt[MAXP];                             // exact: pixels x channels per group < 2^24
@@ -101,14 +101,14 @@ template <typename T>
 __global__ __launch_bounds__(256) void gn_partial_kernel(const GNParams p) {
   constexpr int PC = Chunk<T>::N;
   const int C = p.C0 + p.C1;
-  const int cpg = C / p.groups;
+  const int cpg = p.cpg;                       // (host-prepared, with the divisors: see GNParams)
   const int nvec = C / PC;
-  const int VX = nvec < 256 ? nvec : 256;
-  const int TY = 256 / VX;
+  const int VX = p.vx;
+  const int TY = p.ty;
   const int tid = threadIdx.x;
-  const int tx = tid % VX, ty = tid / VX;
+  const int ty = fd_div(tid, p.fd_vx), tx = tid - ty * VX;
   const int b = blockIdx.y, chunk = blockIdx.x;
-  const int per = (p.HW + p.nchunk - 1) / p.nchunk;
+  const int per = p.per;
   const int p0 = chunk * per;
   const int p1 = min(p.HW, p0 + per);
 
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const GNParams p) {
     int npix = 0, split = PC;
     if (ty < TY && v < nvec) {
       const int c0 = v * PC;
-      const int g0 = c0 / cpg;
+      const int g0 = fd_div(c0, p.fd_cpg);
       split = min(PC, (g0 + 1) * cpg - c0);  // elements [0,split) -> g0, rest -> g0+1
       int pix = p0 + ty;
       if (pix < p1) {
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const GNParams p) {
     const int v_first = max(0, c_lo / PC - 1);                    // (PC is a compile-time power of two)
     const int v_last = min(nvec - 1, (c_lo + cpg - 1) / PC);
     const int npx = p1 - p0;
-    const int np_base = npx / TY, np_rem = npx - np_base * TY;    // thread row y holds np_base + (y < np_rem) pixels
+    const int np_base = npx / TY, np_rem = npx - np_base * TY;   // (one runtime division per workgroup, off the load path)    // thread row y holds np_base + (y < np_rem) pixels
     auto locate = [&](int v, int& it, int& x, int& part, int& cnt) __attribute__((always_inline)) {
       const int c0 = v * PC;
       it = 0; x = v;
@@ -230,19 +230,19 @@ template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const GNParams p) {
   constexpr int PC = Chunk<T>::N;
   const int C = p.C0 + p.C1;
-  const int cpg = C / p.groups;
+  const int cpg = p.cpg;
   const int nvec = C / PC;
   const int b = blockIdx.y;
   __shared__ float s_stat[64][2];
   GNSTAMP(4)
   // every thread owns fixed channel vectors, so the per-channel affine (x*a + b with
   // a = rstd*gamma, b = beta - mean*a) is computed once and the pixel loop is one FMA per element
-  const int VX = nvec < 256 ? nvec : 256;
-  const int TY = 256 / VX;
+  const int VX = p.vx;
+  const int TY = p.ty;
   const int tid = threadIdx.x;
-  const int tx = tid % VX, ty = tid / VX;
+  const int ty = fd_div(tid, p.fd_vx), tx = tid - ty * VX;
   const bool act = ty < TY;
-  const int per = (p.HW + gridDim.x - 1) / gridDim.x;
+  const int per = (p.HW + gridDim.x - 1) / gridDim.x;    // (wave-uniform: one scalar-side division)
   const int p0 = blockIdx.x * per;
   const int p1 = min(p.HW, p0 + per);
   const T* src = nullptr;
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GNParams p) {
       for (int e = 0; e < PC; ++e) { gam[e] = p.gamma[c0 + e]; bet[e] = p.beta[c0 + e]; }
     }
     // a vector spans at most two groups (run_gn checks it): one runtime division per vector, not one per element
-    const int g0 = c0 / cpg;
+    const int g0 = fd_div(c0, p.fd_cpg);
     const int split = min(PC, (g0 + 1) * cpg - c0);
     const float m_lo = s_stat[g0][0], r_lo = s_stat[g0][1];
     const float m_hi = s_stat[split < PC ? g0 + 1 : g0][0], r_hi = s_stat[split < PC ? g0 + 1 : g0][1];
@@ -412,8 +412,8 @@ template <typename T, int MAXU>
 __global__ __launch_bounds__(256) void gn_small_kernel(const GNParams p) {
   constexpr int EPU = 4 / (int)sizeof(T);          // elements per unit
   const int C = p.C0 + p.C1;
-  const int cpg = C / p.groups;
-  const int upg = cpg / EPU;                        // units per pixel of this group
+  const int cpg = p.cpg;
+  const int upg = cpg / EPU;                        // units per pixel of this group (EPU is a power of two)
   const int g = blockIdx.x, b = blockIdx.y;
   const int nunits = p.HW * upg;
   const int c_first = g * cpg;
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const GNParams p) {
   for (int k = 0; k < MAXU; ++k) {
     const int u = threadIdx.x + k * 256;
     if (u < nunits) {
-      const int pix = u / upg, j = u - pix * upg;
+      const int pix = fd_div(u, p.fd_aux), j = u - pix * upg;
       const int c = c_first + j * EPU;
       const T* src = (c < p.C0) ? (const T*)p.src0 + ((size_t)b * p.HW + pix) * p.C0 + c
                                 : (const T*)p.src1 + ((size_t)b * p.HW + pix) * p.C1 + (c - p.C0);
@@ -439,8 +439,7 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const GNParams p) {
   s = wave64_sum(s);
   if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = s;
   __syncthreads();
-  const double n = (double)p.HW * cpg;
-  const float mean = (float)(((double)red[0][0] + (double)red[0][1] + (double)red[0][2] + (double)red[0][3]) / n);
+  const float mean = (float)(((double)red[0][0] + (double)red[0][1] + (double)red[0][2] + (double)red[0][3]) * p.inv_n);
   q = 0.f;
 #pragma unroll
   for (int k = 0; k < MAXU; ++k) {
@@ -452,13 +451,13 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const GNParams p) {
   q = wave64_sum(q);
   if ((threadIdx.x & 63) == 0) red[1][threadIdx.x >> 6] = q;
   __syncthreads();
-  const double var = ((double)red[1][0] + (double)red[1][1] + (double)red[1][2] + (double)red[1][3]) / n;
-  const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
+  const double var = ((double)red[1][0] + (double)red[1][1] + (double)red[1][2] + (double)red[1][3]) * p.inv_n;
+  const float rstd = 1.0f / sqrtf((float)var + p.eps);
 #pragma unroll
   for (int k = 0; k < MAXU; ++k) {
     const int u = threadIdx.x + k * 256;
     if (u < nunits) {
-      const int pix = u / upg, j = u - pix * upg;
+      const int pix = fd_div(u, p.fd_aux), j = u - pix * upg;
       const int c = c_first + j * EPU;
       float y[EPU];
 #pragma unroll
@@ -483,16 +482,16 @@ template <typename T, int MAXV>
 __global__ __launch_bounds__(256) void gn_fused_kernel(const GNParams p, int GB) {
   constexpr int PC = Chunk<T>::N;
   const int C = p.C0 + p.C1;
-  const int cpg = C / p.groups;
-  const int vpp = GB * cpg / PC;                    // vectors per pixel of this group block
-  const int ppi = 256 / vpp;                        // pixels per trip
+  const int cpg = p.cpg;
+  const int vpp = GB * cpg / PC;                    // vectors per pixel of this group block (PC is a power of two)
+  const int ppi = p.ty;                             // pixels per trip = 256 / vpp (host)
   const int b = blockIdx.y;
   const int cfirst = blockIdx.x * GB * cpg;
   const int tid = threadIdx.x;
-  const int j = tid % vpp, pr = tid / vpp;
+  const int pr = fd_div(tid, p.fd_aux), j = tid - pr * vpp;
   const bool active = pr < ppi;
   const int c0 = cfirst + j * PC;                   // first channel of this thread's vector
-  const int glo = (j * PC) / cpg;                   // 0 or 1: block-local group of its first element
+  const int glo = (j * PC) >= cpg ? 1 : 0;          // block-local group of its first element (a block holds 1 or 2 groups)
   const int split = min(PC, (glo + 1) * cpg - j * PC);   // elements [0,split) -> glo, the rest -> glo+1
   const T* src;
   int cs;
@@ -522,11 +521,10 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const GNParams p, int GB)
     if ((tid & 63) == 0) { red[0][tid >> 6] = v0; red[1][tid >> 6] = v1; }
   }
   __syncthreads();
-  const double n = (double)p.HW * cpg;
   float mean[2], rstd[2];
 #pragma unroll
   for (int g = 0; g < 2; ++g)
-    mean[g] = (float)(((double)red[g][0] + (double)red[g][1] + (double)red[g][2] + (double)red[g][3]) / n);
+    mean[g] = (float)(((double)red[g][0] + (double)red[g][1] + (double)red[g][2] + (double)red[g][3]) * p.inv_n);
   {
     const float mlo = glo == 0 ? mean[0] : mean[1], mhi = mean[1];
     float qlo = 0.f, qhi = 0.f;
@@ -547,8 +545,8 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const GNParams p, int GB)
   __syncthreads();
 #pragma unroll
   for (int g = 0; g < 2; ++g) {
-    const double var = ((double)red[2 + g][0] + (double)red[2 + g][1] + (double)red[2 + g][2] + (double)red[2 + g][3]) / n;
-    rstd[g] = (float)(1.0 / sqrt(var + (double)p.eps));
+    const double var = ((double)red[2 + g][0] + (double)red[2 + g][1] + (double)red[2 + g][2] + (double)red[2 + g][3]) * p.inv_n;
+    rstd[g] = 1.0f / sqrtf((float)var + p.eps);
   }
   if (!active) return;
   float a[PC], bb[PC];
@@ -576,10 +574,14 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const GNParams p, int GB)
 }
 
 template <typename T>
-int run_gn(const GNParams& p, hipStream_t s) {
+int run_gn(const GNParams& pin, hipStream_t s) {
   constexpr int PC = Chunk<T>::N;
+  GNParams p = pin;
   const int C = p.C0 + p.C1;
-  if (C % p.groups != 0 || C % PC != 0 || p.C0 % PC != 0 || p.groups > 64) return -2;
+  if (p.groups < 1 || C % p.groups != 0 || C % PC != 0 || p.C0 % PC != 0 || p.groups > 64) return -2;
+  p.cpg = C / p.groups;
+  p.fd_cpg = fastdiv_make(p.cpg);
+  p.inv_n = 1.0 / ((double)p.HW * p.cpg);
   // a 16-B vector may span at most two groups: cpg >= PC, or exactly two whole groups per vector
   // (128 channels in bf16: cpg 4, PC 8 - the image VAE's first level)
   if (C / p.groups < PC && 2 * (C / p.groups) != PC) return -2;
@@ -596,6 +598,8 @@ int run_gn(const GNParams& p, hipStream_t s) {
       if ((p.HW + ppi - 1) / ppi > MAXV) continue;
       if ((long)p.B * (p.groups / GB) < 96) continue;          // too few workgroups to fill the chip
       if (p.HW <= 64 && vpp < 10) continue;                    // 8x8 maps with short runs: gn_small measured faster (8.0 vs 9.7 us)
+      p.ty = ppi;
+      p.fd_aux = fastdiv_make(vpp);
       hipLaunchKernelGGL((gn_fused_kernel<T, MAXV>), dim3(p.groups / GB, p.B), dim3(256), 0, s, p, GB);
       return hipGetLastError() == hipSuccess ? 0 : -3;
     }
@@ -606,14 +610,20 @@ int run_gn(const GNParams& p, hipStream_t s) {
     const long nunits = (long)p.HW * (cpg / EPU);
     // measured: wins for the 8x8 maps (16 -> 9 us), loses from 16x16 up (its 4-byte strided loads)
     if (cpg % EPU == 0 && p.C0 % EPU == 0 && nunits <= 256 * 12 && (long)p.B * p.groups >= 128) {
+      p.fd_aux = fastdiv_make(cpg / EPU);
       hipLaunchKernelGGL((gn_small_kernel<T, 12>), dim3(p.groups, p.B), dim3(256), 0, s, p);
       return hipGetLastError() == hipSuccess ? 0 : -3;
     }
   }
+  const int nvec = C / PC;
+  p.vx = nvec < 256 ? nvec : 256;
+  p.ty = 256 / p.vx;
+  p.fd_vx = fastdiv_make(p.vx);
+  if (p.nchunk < 1) return -2;
+  p.per = (p.HW + p.nchunk - 1) / p.nchunk;
   hipLaunchKernelGGL(gn_partial_kernel<T>, dim3(p.nchunk, p.B), dim3(256), 0, s, p);
   // pixel chunks: >= 4 pixels per thread row, ~2048 workgroups in total
-  const int nvec = C / PC;
-  const int ty = 256 / (nvec < 256 ? nvec : 256);
+  const int ty = p.ty;
   // 16 pixels per thread row (4 unrolled trips) on the big maps, down to 4 when that would leave fewer than ~512
   // workgroups on the chip (every workgroup re-reduces the image's partials first, so fewer and fatter is better)
   int blocks = (p.HW + 16 * ty - 1) / (16 * ty);
