@@ -56,15 +56,13 @@ template <int D, int DP>
 __global__ __launch_bounds__(256) void kv_to_fp8_kernel(const bf16_t* __restrict__ qkv, unsigned char* __restrict__ k8,
                                                         unsigned char* __restrict__ v8, int B, int N, int C, int heads) {
   constexpr int CH = DP / 16;                              // 16-byte output chunks per row
-  const size_t total = (size_t)B * heads * N * CH * 2;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % CH);
-    size_t r = i / CH;
-    const int which = (int)(r & 1);                        // 0 = K, 1 = V
-    r >>= 1;
-    const int tok = (int)(r % N);
-    r /= N;
-    const int h = (int)(r % heads), b = (int)(r / heads);
+  // grid = (token blocks, heads, B): thread -> (token, which, chunk) with compile-time divisors only (the flat-index form
+  // of this loop spent four 64-bit runtime divisions per 16-byte chunk - more instructions than the conversion itself)
+  const int h = blockIdx.y, b = blockIdx.z;
+  constexpr int PER = 2 * CH;                              // work items per token
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N * PER; i += gridDim.x * blockDim.x) {
+    const int tok = i / PER, rem = i - tok * PER;
+    const int which = rem / CH, c = rem - which * CH;      // 0 = K, 1 = V
     const bf16_t* src = qkv + ((size_t)b * N + tok) * 3 * C + (size_t)(1 + which) * C + (size_t)h * D + c * 16;
     float f[16];
 #pragma unroll
@@ -347,10 +345,10 @@ int run8(const void* qkv, void* kv8, void* out, int B, int N, int C, int heads, 
   unsigned char* k8 = (unsigned char*)kv8;
   unsigned char* v8 = k8 + (size_t)B * heads * N * Cfg::DP;
   {
-    const size_t total = (size_t)B * heads * N * (Cfg::DP / 16) * 2;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL((kv_to_fp8_kernel<D, Cfg::DP>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)qkv, k8, v8, B, N, C, heads);
+    const long per_bh = (long)N * (Cfg::DP / 16) * 2;
+    int bx = (int)((per_bh + 255) / 256);
+    if (bx > 256) bx = 256;
+    hipLaunchKernelGGL((kv_to_fp8_kernel<D, Cfg::DP>), dim3(bx, heads, B), dim3(256), 0, s, (const bf16_t*)qkv, k8, v8, B, N, C, heads);
   }
   const size_t lds = (size_t)NST * Cfg::STAGE;
   auto kern = attn_fp8_kernel<D, QF, WPS, NST>;
