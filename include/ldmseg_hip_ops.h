@@ -69,6 +69,9 @@ int ldmseg_igemm_last_kernel(char* buf, int n);
 int ldmseg_igemm_log(int enable);
 int ldmseg_igemm_log_read(char* buf, int n);
 
+/* q[i] = n[i] / d (0 <= n[i] < 2^31, d >= 1) computed the way the kernels divide: host-prepared multiply-shift pair */
+int ldmseg_op_fastdiv(const int* n, int count, int d, int* q, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -45,6 +45,10 @@ struct Temp {
     for (void* p : v) (void)hipFree(p);
   }
 };
+__global__ void fastdiv_probe_kernel(const int* n, int count, FastDiv f, int* q) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) q[i] = fd_div(n[i], f);
+}
 inline size_t es(int dt) { return dt == DT_BF16 ? 2 : 4; }
 inline int bke(int dt) { return dt == DT_BF16 ? 64 : 32; }
 inline int rupi(int v, int a) { return (v + a - 1) / a * a; }
@@ -344,6 +348,13 @@ static int op_igemm_impl(const float* x, const float* x2, const float* w, const 
   return unpack_nhwc(op, out, B, cout, Ho * Wo, cout, dtype, s);
 }
 
+// q[i] = n[i] / d through the multiply-shift divisor the kernels use (FastDiv, kernels.h): exactness test hook
+int ldmseg_op_fastdiv(const int* n, int count, int d, int* q, void* stream) {
+  if (!n || !q || count < 0 || d < 1) return -2;
+  const FastDiv f = fastdiv_make(d);
+  hipLaunchKernelGGL(fastdiv_probe_kernel, dim3((count + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, count, f, q);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
 }  // extern "C"
 namespace ldmseg {
 void ops_bench_knob(int key, int value) {

@@ -92,6 +92,7 @@ SIGNATURES = {
                                 C.POINTER(C.c_float), _vp]),
     "ldmseg_bench_attention": (_i, [_vp, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_float), _vp]),
     "ldmseg_igemm_last_kernel": (_i, [C.c_char_p, _i]),
+    "ldmseg_op_fastdiv": (_i, [_vp, _i, _i, _vp, _vp]),
     "ldmseg_igemm_log": (_i, [_i]),
     "ldmseg_igemm_log_read": (_i, [C.c_char_p, _i]),
 }

@@ -496,3 +496,20 @@ def test_igemm_tile_policies_agree(L, tile_policy, policy, shape):
 
 def test_shipped_policy_is_active_after_the_policy_tests(L):
     assert L.lib().ldmseg_debug_get(1) == L.lib().ldmseg_debug_get(-1)
+
+
+def test_fastdiv_on_device(L):
+    """The kernels' division (host-prepared multiply-shift pair, one v_mul_hi_u32 + shift on the device) against integer
+    division, for the divisors the UNet launches use and for awkward ones, numerators up to 2^31 - 1."""
+    import ctypes as C
+    g = torch.Generator().manual_seed(0)
+    top = 2 ** 31 - 1
+    for d in (1, 2, 3, 7, 10, 45, 64, 160, 180, 320, 1024, 2880, 4096, 40960, 65535, 65537, 999983, 2 ** 30 - 1, 2 ** 30 + 1, top):
+        base = torch.randint(0, top, (4096,), generator=g, dtype=torch.int64)
+        k = torch.randint(0, top // d + 1, (4096,), generator=g, dtype=torch.int64) * d
+        n = torch.cat([base, k, (k - 1).clamp(min=0), (k + 1).clamp(max=top), torch.tensor([0, 1, d - 1, d, top, top - 1])]).clamp(0, top)
+        nd = n.to(torch.int32).cuda()
+        q = torch.empty_like(nd)
+        assert L.lib().ldmseg_op_fastdiv(C.c_void_p(nd.data_ptr()), nd.numel(), d, C.c_void_p(q.data_ptr()), None) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(q.cpu().to(torch.int64), n // d), d
