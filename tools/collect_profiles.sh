@@ -18,7 +18,7 @@ done
 cd $R
 bash tools/trace_layers.sh bf16 8; cp gpurun_out/trace_layers.txt $O/trace_layers_b8_l64_bf16.txt; cp gpurun_out/layers.csv $O/per_launch_events.csv
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
-for u in mfma_lds buf_lds valu_trans; do [ -x tools/ubench/bin/$u ] && timeout 300 tools/ubench/bin/$u > $O/ubench_$u.txt 2>&1; done
+for u in mfma_lds mfma_lds2 buf_lds valu_trans copy_floor; do [ -x tools/ubench/bin/$u ] && timeout 300 tools/ubench/bin/$u > $O/ubench_$u.txt 2>&1; done
 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; tail -2 $O/pytest_gpu.log
 find $O -name "*.db" -delete; find $O -name "*kernel_trace.csv" -size +8M -delete
 du -sh $O

@@ -25,7 +25,7 @@ cp("per_launch_events.csv", "per_launch_events_unet_forward_b8_l64_bf16.csv")
 cp("trace_layers_b8_l64_bf16.txt", "kernel_trace_per_layer_b8_l64_bf16.txt")
 for n in ("pmc_fetch", "pmc_write", "pmc_mfma"):
     cp(n + ".txt", n + ".txt")
-for u in ("mfma_lds", "buf_lds", "valu_trans"):
+for u in ("mfma_lds", "mfma_lds2", "buf_lds", "valu_trans", "copy_floor"):
     cp(f"ubench_{u}.txt", f"ubench_{u}.txt")
 cp("pytest_gpu.log", "pytest_gpu.log")
 
