@@ -243,7 +243,10 @@ int ldmseg_profile_reset(void);
 int ldmseg_profile_dump(const char* path);
 /* measurement knobs (defaults = the shipped configuration): key 1 = igemm tile-policy bits in value[8..12] (and, in
  * -DLDMSEG_IGEMM_ABLATE builds only, phase-ablation flags in value[0..7]); key 2 = attention query-tile choice;
- * keys 3/4 = low/high half of a device buffer for per-workgroup s_memtime stamps (ablate builds). */
+ * keys 3/4 = low/high half of a device buffer for per-workgroup s_memtime stamps (ablate builds); key 5 = run every
+ * igemm launch with that entry of the instantiation list (-1 = off; the launch table and the shape rules are bypassed -
+ * tools/tune_igemm.py); keys 6/7 = ldmseg_bench_igemm only: number of weight copies the timing loop rotates over, and
+ * whether the timed launch carries a folded LayerNorm. */
 int ldmseg_debug_set(int key, int value);
 /* current value of a knob (key 1); key -1 = the shipped default of key 1.  Tests restore through this, never a literal. */
 int ldmseg_debug_get(int key);
