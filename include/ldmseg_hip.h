@@ -13,9 +13,12 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls
  *     only enqueue work.  The one exception is workspace growth: the first call of a
  *     handle at a (B, L) larger than any before (re)allocates its workspace, which
- *     synchronises the device.  ldmseg_unet_reserve() does that up front, after which
- *     forward / sample_loop calls at that size never allocate or synchronise (and are
- *     safe under stream capture).  *_create calls allocate and synchronise.
+ *     synchronises the device.  ldmseg_unet_reserve() does that up front (workspace,
+ *     sampler buffers, the per-device zero page), after which forward / sample_loop
+ *     calls at that size never allocate or synchronise.  The first launch of each
+ *     kernel instantiation in a process still sets a function attribute (host-side,
+ *     no device work): run one warm-up forward before capturing a stream.
+ *     *_create calls allocate and synchronise.
  *   - return 0 on success, negative LDMSEG_E_* on failure; ldmseg_last_error()
  *     returns a thread-local message.  No C++ exception crosses the boundary.
  *   - the library owns handles, repacked weights and workspaces; the caller owns

@@ -21,6 +21,10 @@ using namespace ldmseg;
 namespace {
 
 thread_local std::string g_err;
+// Bumped whenever a process-global tuning knob that the workspace plan depends on changes (ldmseg_debug_set keys 1 / 5:
+// tile policy and forced instantiation decide the split-K slice counts, i.e. the size of the partial-sum scratch).
+// Handles remember the epoch their cached plan was made under and re-plan when it moved.
+int g_plan_epoch = 0;
 int fail(int code, const std::string& msg) {
   g_err = msg;
   return code;
@@ -135,8 +139,10 @@ struct Workspace {  // per-forward activations: persist (bump) + scratch (stack)
   size_t persist_top = 0, scratch_top = 0, scratch_base = 0;
   size_t persist_peak = 0, scratch_peak = 0;
   bool dry = false;
+  bool overflow = false;   // a non-dry request went past the planned capacity (stale plan): the forward fails instead of writing out of range
   void begin(bool dry_, size_t scratch_base_) {
     dry = dry_;
+    overflow = false;
     persist_top = 0;
     scratch_base = scratch_base_;
     scratch_top = 0;
@@ -146,12 +152,14 @@ struct Workspace {  // per-forward activations: persist (bump) + scratch (stack)
     const size_t off = persist_top;
     persist_top += rup(bytes, 256);
     if (persist_top > persist_peak) persist_peak = persist_top;
+    if (!dry && persist_top > (scratch_base ? scratch_base : cap)) { overflow = true; return base; }
     return dry ? (void*)(uintptr_t)(0x1000 + off) : base + off;
   }
   void* scratch(size_t bytes) {
     const size_t off = scratch_top;
     scratch_top += rup(bytes, 256);
     if (scratch_top > scratch_peak) scratch_peak = scratch_top;
+    if (!dry && scratch_base + scratch_top > cap) { overflow = true; return base; }
     return dry ? (void*)(uintptr_t)(0x1000 + off) : base + scratch_base + off;
   }
   size_t mark() const { return scratch_top; }
@@ -259,6 +267,8 @@ struct Exec {
   hipStream_t s;
   int attn_fp8_min_tokens = 0;
   bool dry() const { return ws->dry; }
+  // a request beyond the planned workspace (a plan made under other tuning knobs): fail before anything is launched on it
+  int ws_ok() const { return ws->overflow ? fail(LDMSEG_E_OOM, "workspace plan exceeded (stale plan): nothing was launched") : 0; }
 
   Act new_act(int C, int H, int W, bool persist) {
     Act a;
@@ -287,6 +297,7 @@ struct Exec {
               " epi=" + std::to_string(p.epi) + " splits=" + std::to_string(p.splits);
     ProfScope ps(0, s, flops, bytes, dry(), label);
     if (dry()) return 0;
+    TRY(ws_ok());
     return launch_igemm(p, dt, s);
   }
 
@@ -329,6 +340,7 @@ struct Exec {
     const double bytes = 3.0 * B * g.HW * ctot * esize(dt);
     ProfScope ps(2, s, 0, bytes, dry(), "HW=" + std::to_string(g.HW) + " C=" + std::to_string(ctot));
     if (dry()) return 0;
+    TRY(ws_ok());
     return launch_groupnorm(g, dt, s);
   }
 
@@ -337,6 +349,7 @@ struct Exec {
     const int M = B * x.H * x.W;
     ProfScope ps(3, s, 0, 1.0 * M * x.C * esize(dt), dry());
     if (dry()) return 0;
+    TRY(ws_ok());
     return launch_rowstats(x.p, stats, M, x.C, eps, dt, s);
   }
 
@@ -345,6 +358,7 @@ struct Exec {
     const int M = B * x.H * x.W;
     ProfScope ps(3, s, 0, 2.0 * M * x.C * esize(dt), dry());
     if (dry()) return 0;
+    TRY(ws_ok());
     return launch_layernorm(x.p, out->p, n.g, n.b, M, x.C, eps, silu, dt, s);
   }
 };
@@ -385,7 +399,7 @@ struct ldmseg_unet {
   TransformerW down_attn[3][2], mid_attn, up_attn[4][3];  // up_attn[0] unused
   ConvW down_conv[3], up_conv[3];
   // sampler state
-  int plan_B = 0, plan_L = 0;
+  int plan_B = 0, plan_L = 0, plan_epoch = -1;
   size_t plan_persist = 0, plan_scratch = 0;
   int attn_fp8_min_tokens = 0;   // > 0: bf16 mode runs attention levels with N >= this many tokens on the fp8 operand path
   float* cond = nullptr;   // [B,4,L,L] self-conditioning channel
@@ -616,8 +630,10 @@ int run_transformer(Exec& ex, const TransformerW& t, const Act& x, Act* out) {
                            ? attention_fp8_scratch_bytes(ex.B, N, C, 8) : 0;
     if (kv8) {                                     // long-context level on the fp8 operand path (BASELINE configs[4])
       void* scratch = ws->scratch(kv8);
+      if (!ex.dry()) TRY(ex.ws_ok());
       if (!ex.dry()) TRY(launch_attention_fp8(qkv.p, scratch, att.p, ex.B, N, C, 8, ex.s));
     } else if (!ex.dry()) {
+      TRY(ex.ws_ok());
       TRY(launch_attention(qkv.p, att.p, ex.B, N, C, 8, ex.dt, ex.s));
     }
   }
@@ -676,6 +692,7 @@ int unet_forward_impl(ldmseg_unet* u, const float* a, int Ca, const float* b, in
   {
     ProfScope ps(4, s, 0, 0, dry);
     if (!dry) {
+      TRY(ex.ws_ok());
       TRY(launch_time_embed(t_dev, t_count, t_host, TB, sinus, s));
       TRY(launch_small_linear(sinus, u->te1_w, u->te1_b, e1, TB, 320, kTimeDim, 0, 1, s));
       TRY(launch_small_linear(e1, u->te2_w, u->te2_b, emb, TB, kTimeDim, kTimeDim, 0, 0, s));
@@ -688,6 +705,7 @@ int unet_forward_impl(ldmseg_unet* u, const float* a, int Ca, const float* b, in
   Act xin = ex.new_act(bke(dt), L, L, true);
   {
     ProfScope ps(4, s, 0, 0, dry);
+    if (!dry) TRY(ex.ws_ok());
     if (!dry) TRY(launch_pack_concat3(a, Ca, b, Cb, c, Cc, xin.p, B, L * L, bke(dt), dt, s));
   }
   Act h;
@@ -769,12 +787,13 @@ int ensure_ws(void** mem, size_t* cap, Workspace* ws, size_t need) {
 int unet_forward_checked(ldmseg_unet* u, const float* a, int Ca, const float* b, int Cb, const float* c, int Cc,
                          const int64_t* t_dev, int t_count, int64_t t_host, int B, int L, float* out, hipStream_t s) {
   // measure (cached per shape), (re)allocate, run
-  if (u->plan_B != B || u->plan_L != L) {
+  if (u->plan_B != B || u->plan_L != L || u->plan_epoch != g_plan_epoch) {
     TRY(unet_forward_impl(u, a, Ca, b, Cb, c, Cc, t_dev, t_count, t_host, B, L, out, s, true, 0));
     u->plan_persist = rup(u->ws.persist_peak, 4096);
     u->plan_scratch = rup(u->ws.scratch_peak, 4096);
     u->plan_B = B;
     u->plan_L = L;
+    u->plan_epoch = g_plan_epoch;
   }
   TRY(ensure_ws(&u->ws_mem, &u->ws_cap, &u->ws, u->plan_persist + u->plan_scratch));
   return unet_forward_impl(u, a, Ca, b, Cb, c, Cc, t_dev, t_count, t_host, B, L, out, s, false, u->plan_persist);
@@ -1149,7 +1168,8 @@ int ldmseg_unet_create(const ldmseg_unet_cfg* cfg, int n_weights, const char* co
   ldmseg_unet* u = new ldmseg_unet();
   u->cfg = *cfg;
   u->dt = cfg->compute_dtype == LDMSEG_BF16 ? DT_BF16 : DT_F32;
-  const int r = unet_build(u, wm);
+  int r = unet_build(u, wm);
+  if (r == 0) r = igemm_warm();
   if (r != 0) { delete u; return r; }
   *out = u;
   return 0;
@@ -1199,7 +1219,8 @@ int ldmseg_vae_create(const ldmseg_vae_cfg* cfg, int n_weights, const char* cons
   ldmseg_vae* v = new ldmseg_vae();
   v->cfg = *cfg;
   v->dt = cfg->compute_dtype == LDMSEG_BF16 ? DT_BF16 : DT_F32;
-  const int r = vae_build(v, wm);
+  int r = vae_build(v, wm);
+  if (r == 0) r = igemm_warm();
   if (r != 0) { delete v; return r; }
   *out = v;
   return 0;
@@ -1257,7 +1278,8 @@ int ldmseg_vae_image_create(const ldmseg_vae_image_cfg* cfg, int n_weights, cons
   ldmseg_vae_image* v = new ldmseg_vae_image();
   v->cfg = *cfg;
   v->dt = cfg->compute_dtype == LDMSEG_BF16 ? DT_BF16 : DT_F32;
-  const int r = klenc_build(v, wm);
+  int r = klenc_build(v, wm);
+  if (r == 0) r = igemm_warm();
   if (r != 0) { delete v; return r; }
   *out = v;
   return 0;
@@ -1353,15 +1375,17 @@ int ldmseg_unet_reserve(ldmseg_unet* h, int B, int L) {
   if (B < 1 || L < 8 || L % 8 != 0) return fail(LDMSEG_E_SHAPE, "L must be a positive multiple of 8, B >= 1");
   DeviceGuard dg(h->cfg.device);
   const int ci = h->cfg.in_channels;
-  if (h->plan_B != B || h->plan_L != L) {
+  if (h->plan_B != B || h->plan_L != L || h->plan_epoch != g_plan_epoch) {
     TRY(unet_forward_impl(h, nullptr, ci, nullptr, 0, nullptr, 0, nullptr, 1, 0, B, L, nullptr, nullptr, true, 0));
     h->plan_persist = rup(h->ws.persist_peak, 4096);
     h->plan_scratch = rup(h->ws.scratch_peak, 4096);
     h->plan_B = B;
     h->plan_L = L;
+    h->plan_epoch = g_plan_epoch;
   }
   TRY(ensure_ws(&h->ws_mem, &h->ws_cap, &h->ws, h->plan_persist + h->plan_scratch));
   TRY(loop_reserve(h, (size_t)B * 4 * L * L));
+  TRY(igemm_warm());
   return 0;
 }
 
@@ -1466,8 +1490,8 @@ int ldmseg_profile_read(int family, int64_t* launches, double* total_ms, double*
 // tuning knobs for experiments: key 0 = igemm K-loop ring depth (2, 3, 4)
 int ldmseg_debug_set(int key, int value) {
   if (key == 2) { attention_set_qf1(value); return 0; }
-  if (key == 1) { igemm_set_dbg(value); return 0; }
-  if (key == 5) { igemm_force_cfg(value); return 0; }   // tools/tune_igemm.py: entry of igemm's instantiation list, -1 = off
+  if (key == 1) { igemm_set_dbg(value); ++g_plan_epoch; return 0; }
+  if (key == 5) { igemm_force_cfg(value); ++g_plan_epoch; return 0; }   // tools/tune_igemm.py: entry of igemm's instantiation list, -1 = off
   if (key == 6 || key == 7) { ops_bench_knob(key, value); return 0; }   // ldmseg_bench_igemm: 6 = weight copies rotated, 7 = folded-LN launch   // bits 0-7 ablation flags (LDMSEG_IGEMM_ABLATE builds), bits 8-12 tile policy
   static unsigned long long ts_ptr = 0;                // keys 3/4: low/high half of a device stamp buffer (ablate builds)
   if (key == 3) { ts_ptr = (ts_ptr & 0xffffffff00000000ull) | (unsigned)value; igemm_set_tsbuf((void*)(uintptr_t)ts_ptr); return 0; }

@@ -83,6 +83,7 @@ struct IgemmParams {
 // returns 0 or a negative error (bad shape)
 int launch_igemm(const IgemmParams& p, int dtype, hipStream_t s);
 size_t igemm_partial_bytes(const IgemmParams& p);
+int igemm_warm();   // per-device lazy state (zero page) created now instead of inside the first launch
 int igemm_plan_splits(const IgemmParams& p, int dtype);
 void attention_set_qf1(int v);    // tuning knob: force 16 query rows per wave
 void igemm_set_tsbuf(void* dev_buf);   // LDMSEG_IGEMM_ABLATE builds only

@@ -619,7 +619,9 @@ int run_gn(const GNParams& pin, hipStream_t s) {
   p.vx = nvec < 256 ? nvec : 256;
   p.ty = 256 / p.vx;
   p.fd_vx = fastdiv_make(p.vx);
-  if (p.nchunk < 1) return -2;
+  // the two-launch path combines statistics with 8 lanes per group in a 256-thread workgroup (32 groups) and keeps
+  // at most 128 chunk partials per lane set (gn_reduce_stats: MAXP = 16 x 8 lanes)
+  if (p.nchunk < 1 || p.nchunk > 128 || p.groups > 32) return -2;
   p.per = (p.HW + p.nchunk - 1) / p.nchunk;
   hipLaunchKernelGGL(gn_partial_kernel<T>, dim3(p.nchunk, p.B), dim3(256), 0, s, p);
   // pixel chunks: >= 4 pixels per thread row, ~2048 workgroups in total

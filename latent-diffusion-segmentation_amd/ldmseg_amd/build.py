@@ -3,6 +3,7 @@
 The shared library is written in-tree (next to this file) so that it travels with
 the repository snapshot to the GPU box; it is git-ignored.
 """
+import hashlib
 import os
 import subprocess
 import sys
@@ -29,15 +30,27 @@ def _hipcc():
     raise RuntimeError("hipcc not found")
 
 
-def _stale(target, deps):
-    if not os.path.exists(target):
-        return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+def _digest(cmd, deps):
+    """Identity of one compile: the command line (compiler, flags, output) and the bytes of the source and every header."""
+    h = hashlib.sha256("\0".join(cmd).encode())
+    for d in deps:
+        with open(d, "rb") as f:
+            h.update(b"\0" + os.path.basename(d).encode() + b"\0" + f.read())
+    return h.hexdigest()
+
+
+def _current(target, stamp, digest):
+    if not (os.path.exists(target) and os.path.exists(stamp)):
+        return False
+    with open(stamp) as f:
+        return f.read().strip() == digest
 
 
 def build_library(force=False, verbose=False):
-    """Compile every .hip source and link the shared library. Returns its path."""
+    """Compile every .hip source and link the shared library. Returns its path.
+
+    An object is rebuilt when the hash of (command line, source, headers) differs from the one recorded next to it, so a
+    flag change or a touched-but-identical file behaves correctly (mtimes are not consulted)."""
     hipcc = _hipcc()
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
@@ -49,8 +62,10 @@ def build_library(force=False, verbose=False):
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(o)
-        if force or _stale(o, [s] + headers):
-            jobs.append([hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", s, "-o", o])
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", s, "-o", o]
+        dig = _digest(cmd, [s] + headers)
+        if force or not _current(o, o + ".sha", dig):
+            jobs.append((cmd, o + ".sha", dig))
 
     def run(cmd):
         if verbose:
@@ -59,10 +74,27 @@ def build_library(force=False, verbose=False):
         if r.returncode != 0:
             raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stderr[-4000:])
 
+    def compile_one(job):
+        cmd, stamp, dig = job
+        if os.path.exists(stamp):
+            os.remove(stamp)
+        run(cmd)
+        with open(stamp, "w") as f:
+            f.write(dig)
+
     with ThreadPoolExecutor(max_workers=max(1, min(6, os.cpu_count() or 1))) as ex:
-        list(ex.map(run, jobs))
-    if jobs or force or _stale(LIB_PATH, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs)
+        list(ex.map(compile_one, jobs))
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    h = hashlib.sha256("\0".join(link).encode())
+    for o in objs:
+        with open(o + ".sha") as f:
+            h.update(f.read().encode())
+    ldig = h.hexdigest()
+    lstamp = os.path.join(objdir, "lib.sha")
+    if jobs or force or not _current(LIB_PATH, lstamp, ldig):
+        run(link)
+        with open(lstamp, "w") as f:
+            f.write(ldig)
     return LIB_PATH
 
 

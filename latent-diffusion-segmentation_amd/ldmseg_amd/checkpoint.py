@@ -46,23 +46,33 @@ def vae_state_from(data: dict) -> "OrderedDict[str, torch.Tensor]":
     return OrderedDict((k, sd[k]) for k in schema)
 
 
-def _load(path: str):
-    """Tensors-only unpickling first; the reference's checkpoints also pickle the config dict `p` (plain python
-    containers, fine) and, in some runs, optimizer / scaler objects - only those fall back to the full unpickler."""
+def _load(path: str, allow_pickle: Optional[bool] = None):
+    """Tensors-only unpickling (``weights_only=True``).  The reference's checkpoints also pickle the config dict `p`
+    (plain python containers: accepted by the safe loader) and, in some runs, optimizer / scaler objects that it refuses.
+    The full unpickler executes code from the file, so it runs only on an explicit opt-in: ``allow_pickle=True`` or the
+    environment variable ``LDMSEG_ALLOW_PICKLE=1``; I/O errors (missing / truncated file) are never retried."""
+    import os
+    import pickle
+    if allow_pickle is None:
+        allow_pickle = os.environ.get("LDMSEG_ALLOW_PICKLE", "0") == "1"
     try:
         return torch.load(path, map_location="cpu", weights_only=True)
-    except Exception:
+    except pickle.UnpicklingError as e:
+        if not allow_pickle:
+            raise pickle.UnpicklingError(
+                f"{path}: refused by the tensors-only loader ({e}); pass allow_pickle=True or set LDMSEG_ALLOW_PICKLE=1 "
+                "to unpickle a checkpoint you trust") from e
         return torch.load(path, map_location="cpu", weights_only=False)
 
 
-def load_ldm_checkpoint(path: str, use_ema: bool = False):
-    data = _load(path)
+def load_ldm_checkpoint(path: str, use_ema: bool = False, allow_pickle: Optional[bool] = None):
+    data = _load(path, allow_pickle)
     return {"unet": unet_state_from(data, use_ema), "vae_semseg": vae_state_from(data) if "vae_semseg" in data else None,
             "p": data.get("p"), "step": data.get("step"), "epoch": data.get("epoch")}
 
 
-def load_ae_checkpoint(path: str):
-    data = _load(path)
+def load_ae_checkpoint(path: str, allow_pickle: Optional[bool] = None):
+    data = _load(path, allow_pickle)
     return vae_state_from(data)
 
 
