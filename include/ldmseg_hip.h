@@ -135,6 +135,20 @@ int ldmseg_vae_decode(ldmseg_vae* h, const float* z, float z_scale, int B, int L
  * max_prob [B,8L,8L] fp32 or NULL. */
 int ldmseg_vae_decode_argmax(ldmseg_vae* h, const float* z, float z_scale, int B, int L, float mask_th, int64_t ignore_label,
                              int64_t* ids, float* max_prob, void* stream);
+/* The evaluation tail of TrainerDiffusion.compute_pq (trainers_ldm_cond.py:1243-1313) in one call, without the
+ * [B,128,H,W] fp32 logits: decode (vae.py:267-271 incl. the bilinear x2) -> F.interpolate to the network input size
+ * (in_h, in_w) (:1252-1257) -> crop_padding (:1172-1178, :1263) -> F.interpolate to the original size (h_b, w_b)
+ * (:1266-1271) -> argmax / thresholds / segment filtering (:1277-1313, see ldmseg_panoptic_postprocess below).  The
+ * three bilinear stages (all align_corners=False) are evaluated as one separable weighted sum over the decoder's 4L map.
+ *   crop_boxes  [B][4] HOST int32 (y0, x0, height, width) of the non-padded box in the (in_h, in_w) grid; NULL = whole grid
+ *   out_sizes   [B][2] HOST int32 (h_b, w_b);  out_offsets [B] HOST int64: first element of image b in labels / panoptic
+ *   labels, panoptic: flat int32 device buffers holding the ragged [h_b * w_b] maps; keep / counts / mask_counts [B,C]
+ * as in ldmseg_panoptic_postprocess.  Enqueues 2B + 2 small launches behind the decoder. */
+int ldmseg_vae_decode_panoptic(ldmseg_vae* h, const float* z, float z_scale, int B, int L, int in_h, int in_w,
+                               const int32_t* crop_boxes, const int32_t* out_sizes, const int64_t* out_offsets,
+                               int threshold_output, int threshold_mode, float mask_th, int count_th, double overlap_th,
+                               int64_t ignore_label, int32_t* labels, int32_t* panoptic, uint8_t* keep, int32_t* counts,
+                               int32_t* mask_counts, void* stream);
 /* Panoptic post-processing of the evaluation loop (trainers_ldm_cond.py:1277-1313) on logits [B,C,H,W] fp32 that
  * are already at the output size (C <= 256):
  *   labels   [B,H,W] int32  argmax over C; -1 where threshold_output and (threshold_mode 0: max softmax prob,

@@ -40,6 +40,15 @@ int ldmseg_op_convt2(const float* x, const float* w, const float* bias, int B, i
 /* F.interpolate(scale_factor=2, mode='bilinear', align_corners=False)  (vae.py:270) */
 int ldmseg_op_bilinear2x(const float* x, int B, int C, int H, int W, int dtype, float* out, void* stream);
 
+/* The fused evaluation tail of ldmseg_vae_decode_panoptic on a given decoder output x4 [B,C,H4,W4] (f32 NCHW, packed to
+ * NHWC `dtype` first); host geometry arrays as there.  volume (optional, device): the resampled logits [C][h_b*w_b] of
+ * image b at C * out_offsets[b] - lets a test compare the interpolation chain with F.interpolate o crop o F.interpolate. */
+int ldmseg_op_panoptic_from_decoder(const float* x4, int B, int C, int H4, int W4, int dtype, int in_h, int in_w,
+                                    const int32_t* crop_boxes, const int32_t* out_sizes, const int64_t* out_offsets,
+                                    int threshold_output, int threshold_mode, float mask_th, int count_th, double overlap_th,
+                                    int64_t ignore_label, int32_t* labels, int32_t* panoptic, uint8_t* keep, int32_t* counts,
+                                    int32_t* mask_counts, float* volume, void* stream);
+
 /* One conv / GEMM layer launched exactly as the engine launches it inside a forward (NHWC operands, the engine's
  * split-K plan when splits == 0, row-major store epilogue with bias / per-image bias row / residual / SiLU, or GEGLU):
  * F.conv2d(cat([x,x2],1) [nearest x2 if up], w, bias, stride, k/2) + rowbias[b,:,None,None] + resid, then SiLU;
@@ -58,6 +67,8 @@ int ldmseg_op_ln_linear(const float* x, const float* gamma, const float* beta, c
 int ldmseg_bench_igemm(const float* x, const float* x2, const float* w, const float* bias, const float* resid,
                        const float* rowbias, int B, int Ci, int Ci2, int H, int W, int Co, int k, int stride, int up, int geglu,
                        int silu, int splits, int dtype, int iters, float* us_per_launch, void* stream);
+int ldmseg_bench_groupnorm(const float* gamma, const float* beta, int B, int C, int C2, int HW, int silu, int dtype, int iters,
+                           float* us_per_launch, void* stream);
 int ldmseg_bench_attention(const float* qkv, int B, int N, int C, int heads, int dtype, int iters, float* us_per_launch,
                            void* stream);
 /* "igemm<dtype,BM,BN,WM,WN,NST,PIPE,LDR> splits=S grid=G": template instantiation and plan of the most recent igemm

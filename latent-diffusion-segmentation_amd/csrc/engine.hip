@@ -896,9 +896,17 @@ int vae_build(ldmseg_vae* v, const WeightMap& wm) {
 }
 
 struct ArgmaxOut { int64_t* ids = nullptr; float* prob = nullptr; float mask_th = -1.f; int64_t ignore_label = 0; };
+// fused evaluation tail (ldmseg_vae_decode_panoptic): host-side per-image geometry + device outputs
+struct PanopticOut {
+  int in_h = 0, in_w = 0;
+  const int32_t* boxes = nullptr; const int32_t* sizes = nullptr; const int64_t* offsets = nullptr;
+  int threshold_output = 0, threshold_mode = 0;
+  float mask_th = 0.5f; int count_th = 0; double overlap_th = 0.0; int64_t ignore_label = 0;
+  int32_t* labels = nullptr; int32_t* panoptic = nullptr; uint8_t* keep = nullptr; int32_t* counts = nullptr; int32_t* mask_counts = nullptr;
+};
 
 int vae_decode_impl(ldmseg_vae* v, const float* z, float z_scale, int B, int L, int interpolate, float* logits,
-                    hipStream_t s, bool dry, size_t scratch_base, const ArgmaxOut* am = nullptr) {
+                    hipStream_t s, bool dry, size_t scratch_base, const ArgmaxOut* am = nullptr, const PanopticOut* po = nullptr) {
   Workspace* ws = &v->ws;
   ws->begin(dry, scratch_base);
   Exec ex{ws, v->dt, B, s};
@@ -930,7 +938,21 @@ int vae_decode_impl(ldmseg_vae* v, const float* z, float z_scale, int B, int L, 
   p.src0 = g.p; p.C0 = g.C; p.B = B; p.Hi = p.Ho = H4; p.Wi = p.Wo = W4;
   p.taps = 9; p.M = B * H4 * W4; p.N = v->dec_out.N; p.n_valid = c.out_channels;
   p.W = v->dec_out.w; p.bias = v->dec_out.bias;
-  if (am) {   // fused tail: NHWC logits at 4L -> bilinear x2 + argmax + max-softmax, no logits tensor
+  if (po) {   // fused evaluation tail: NHWC logits at 4L -> (x2, input size, crop, original size) resampling + panoptic post-processing
+    Act lo = ex.new_act(c.out_channels, H4, W4, false);
+    p.out = lo.p; p.ldo = c.out_channels; p.epi = EPI_STORE;
+    TRY(ex.igemm(p));
+    ProfScope ps(4, s, 0, (double)B * H4 * W4 * c.out_channels * esize(dt), dry);
+    if (!dry) {
+      TRY(ex.ws_ok());
+      const int r = launch_panoptic_from_decoder(lo.p, B, H4, W4, c.out_channels, dt, po->in_h, po->in_w, po->boxes, po->sizes,
+                                                 po->offsets, po->threshold_output, po->threshold_mode, po->mask_th, po->count_th,
+                                                 po->overlap_th, po->ignore_label, po->labels, po->panoptic, po->keep, po->counts,
+                                                 po->mask_counts, s);
+      if (r == -2) return fail(LDMSEG_E_ARG, "decode_panoptic: bad crop box / output size / class count");
+      TRY(r);
+    }
+  } else if (am) {   // fused tail: NHWC logits at 4L -> bilinear x2 + argmax + max-softmax, no logits tensor
     Act lo = ex.new_act(c.out_channels, H4, W4, false);
     p.out = lo.p; p.ldo = c.out_channels; p.epi = EPI_STORE;
     TRY(ex.igemm(p));
@@ -1254,6 +1276,29 @@ int ldmseg_vae_decode_argmax(ldmseg_vae* h, const float* z, float z_scale, int B
   return vae_decode_impl(h, z, z_scale, B, L, 1, nullptr, (hipStream_t)stream, false, persist, &am);
 }
 
+int ldmseg_vae_decode_panoptic(ldmseg_vae* h, const float* z, float z_scale, int B, int L, int in_h, int in_w,
+                               const int32_t* crop_boxes, const int32_t* out_sizes, const int64_t* out_offsets,
+                               int threshold_output, int threshold_mode, float mask_th, int count_th, double overlap_th,
+                               int64_t ignore_label, int32_t* labels, int32_t* panoptic, uint8_t* keep, int32_t* counts,
+                               int32_t* mask_counts, void* stream) {
+  g_err.clear();
+  if (!h || !z || !out_sizes || !out_offsets || !labels || !panoptic || !keep || !counts || !mask_counts)
+    return fail(LDMSEG_E_ARG, "null argument");
+  if (B < 1 || L < 1 || in_h < 1 || in_w < 1) return fail(LDMSEG_E_SHAPE, "bad B/L/input size");
+  if (threshold_mode != 0 && threshold_mode != 1) return fail(LDMSEG_E_ARG, "threshold_mode must be 0 (max) or 1 (topk_diff)");
+  if (h->cfg.num_upscalers != 2) return fail(LDMSEG_E_ARG, "the fused tail assumes interpolation_factor 2 (num_upscalers 2)");
+  DeviceGuard dg(h->cfg.device);
+  PanopticOut po;
+  po.in_h = in_h; po.in_w = in_w; po.boxes = crop_boxes; po.sizes = out_sizes; po.offsets = out_offsets;
+  po.threshold_output = threshold_output; po.threshold_mode = threshold_mode; po.mask_th = mask_th; po.count_th = count_th;
+  po.overlap_th = overlap_th; po.ignore_label = ignore_label;
+  po.labels = labels; po.panoptic = panoptic; po.keep = keep; po.counts = counts; po.mask_counts = mask_counts;
+  TRY(vae_decode_impl(h, z, z_scale, B, L, 1, nullptr, (hipStream_t)stream, true, 0, nullptr, &po));
+  const size_t persist = rup(h->ws.persist_peak, 4096), scratch = rup(h->ws.scratch_peak, 4096);
+  TRY(ensure_ws(&h->ws_mem, &h->ws_cap, &h->ws, persist + scratch));
+  return vae_decode_impl(h, z, z_scale, B, L, 1, nullptr, (hipStream_t)stream, false, persist, nullptr, &po);
+}
+
 int ldmseg_vae_encode(ldmseg_vae* h, const float* x, float in_mul, float in_add, int B, int H, float* moments,
                       void* stream) {
   g_err.clear();
@@ -1492,6 +1537,8 @@ int ldmseg_debug_set(int key, int value) {
   if (key == 2) { attention_set_qf1(value); return 0; }
   if (key == 1) { igemm_set_dbg(value); ++g_plan_epoch; return 0; }
   if (key == 5) { igemm_force_cfg(value); ++g_plan_epoch; return 0; }   // tools/tune_igemm.py: entry of igemm's instantiation list, -1 = off
+  if (key == 8) { groupnorm_set_variant(value); return 0; }
+  if (key == 8) { groupnorm_set_variant(value); return 0; }
   if (key == 6 || key == 7) { ops_bench_knob(key, value); return 0; }   // ldmseg_bench_igemm: 6 = weight copies rotated, 7 = folded-LN launch   // bits 0-7 ablation flags (LDMSEG_IGEMM_ABLATE builds), bits 8-12 tile policy
   static unsigned long long ts_ptr = 0;                // keys 3/4: low/high half of a device stamp buffer (ablate builds)
   if (key == 3) { ts_ptr = (ts_ptr & 0xffffffff00000000ull) | (unsigned)value; igemm_set_tsbuf((void*)(uintptr_t)ts_ptr); return 0; }

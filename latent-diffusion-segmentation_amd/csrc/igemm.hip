@@ -976,8 +976,9 @@ inline bool mid8_ok(long t128, int splits) {
 //   1  256 rows, 8 waves, pipelined K loop       4  128 rows, 8 waves, pipelined K loop
 //   2  256 rows, 8 waves, plain K loop           5  128 rows, 4 waves, 4-stage ring (one workgroup per CU)
 //   6  64 rows, 4 waves, 4-stage ring            7  64 rows, 4 waves, two workgroups per CU
-//   8  128 rows, 4 waves, two workgroups per CU
-constexpr int kNumCfg = 9;
+//   8  128 rows, 4 waves, two workgroups per CU  9  64 rows, 8 waves (16 x 80 wave tiles), 4-stage ring
+//   10 64 rows, 8 waves, 3-stage ring
+constexpr int kNumCfg = 11;
 template <typename T, int BN, bool LNF>
 int run_cfg(int cfg, const IgemmParams& p, hipStream_t s) {
   switch (cfg) {
@@ -990,6 +991,8 @@ int run_cfg(int cfg, const IgemmParams& p, hipStream_t s) {
     default: break;
   }
   if constexpr (!LNF) {
+    if (cfg == 9) return run<T, 64, BN, 4, 2, 4>(p, s);
+    if (cfg == 10) return run<T, 64, BN, 4, 2, 3>(p, s);
     switch (cfg) {
       case 2: return run<T, 256, BN, 4, 2, 3, false>(p, s);
       case 3: return run<T, 128, BN, 2, 2, 4, true, 4>(p, s);

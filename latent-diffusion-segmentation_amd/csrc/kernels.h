@@ -116,6 +116,8 @@ struct GNParams {
 };
 int gn_nchunk(int B, int HW);
 int launch_groupnorm(const GNParams& p, int dtype, hipStream_t s);
+void groupnorm_set_variant(int v);   // tuning knob: bit0 = 64x64 maps on the two-launch path (no slab kernel), bit2 = 12-wave slab workgroups
+void groupnorm_set_variant(int v);   // tuning knob: bit0 = no 16-wave slab kernel (64x64 maps on the two-launch path), bit1 = slab kernel on the small maps too
 
 // LayerNorm over the last dim of [M][C] (+ optional SiLU) - also LayerNorm2d in NHWC
 int launch_layernorm(const void* x, void* y, const float* gamma, const float* beta, int M, int C,
@@ -182,6 +184,12 @@ int launch_axpby(const float* x, float a, float b, float* y, size_t n, hipStream
 int launch_panoptic_postprocess(const float* logits, int B, int C, int HW, int threshold_output, int threshold_mode,
                                 float mask_th, int count_th, double overlap_th, int64_t ignore_label, int32_t* labels,
                                 int32_t* panoptic, uint8_t* keep, int32_t* counts, int32_t* mask_counts, hipStream_t s);
+// fused evaluation tail on the decoder's 4L NHWC output: x2 -> input size -> crop -> original size -> panoptic post-processing
+int launch_panoptic_from_decoder(const void* x4, int B, int H4, int W4, int C, int dtype, int in_h, int in_w,
+                                 const int32_t* boxes_host, const int32_t* sizes_host, const int64_t* offsets_host,
+                                 int threshold_output, int threshold_mode, float mask_th, int count_th, double overlap_th,
+                                 int64_t ignore_label, int32_t* labels, int32_t* panoptic, uint8_t* keep, int32_t* counts,
+                                 int32_t* mask_counts, hipStream_t s, float* volume = nullptr);   // volume: test hook, [sum_b C * h_b * w_b] fp32
 int launch_bit_encode(const int64_t* ids, float* out, uint8_t* ignore, int B, int n, int HW, int64_t ignore_label,
                       float fill, float mul, float add, hipStream_t s);
 int launch_bit_decode(const float* x, int64_t* out, int B, int n, int HW, hipStream_t s);

@@ -697,6 +697,8 @@ int gn_nchunk(int B, int HW) {
   return n;
 }
 
+void groupnorm_set_variant(int) {}   // (tuning hook of measured-and-rejected variants: tools/experiments/r03_groupnorm_register_slab_kernel.patch)
+
 int launch_groupnorm(const GNParams& p, int dtype, hipStream_t s) {
   return dtype == DT_BF16 ? run_gn<bf16_t>(p, s) : run_gn<float>(p, s);
 }

@@ -184,6 +184,59 @@ int ldmseg_op_groupnorm(const float* x, const float* x2, const float* gamma, con
   return unpack_nhwc(op, out, B, C + C2, HW, C + C2, dtype, s);
 }
 
+// timing of one GroupNorm launch shape the way the engine launches it (tools/kbench.py gn): average microseconds over
+// `iters` back-to-back launches between two HIP events; the input is whatever the allocation holds (statistics of garbage
+// cost the same), gamma / beta are [C + C2] device vectors
+int ldmseg_bench_groupnorm(const float* gamma, const float* beta, int B, int C, int C2, int HW, int silu, int dtype, int iters,
+                           float* us_per_launch, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  Temp t;
+  void* xp = t.get((size_t)B * HW * C * es(dtype));
+  void* x2p = C2 ? t.get((size_t)B * HW * C2 * es(dtype)) : nullptr;
+  void* op = t.get((size_t)B * HW * (C + C2) * es(dtype));
+  if (!xp || !op || (C2 && !x2p)) return -3;
+  (void)hipMemsetAsync(xp, 0x3c, (size_t)B * HW * C * es(dtype), s);
+  if (C2) (void)hipMemsetAsync(x2p, 0x3c, (size_t)B * HW * C2 * es(dtype), s);
+  GNParams g;
+  g.src0 = xp; g.C0 = C; g.src1 = x2p; g.C1 = C2; g.B = B; g.HW = HW; g.gamma = gamma; g.beta = beta; g.eps = 1e-5f;
+  g.silu = silu; g.out = op; g.nchunk = gn_nchunk(B, HW);
+  g.partial = (float*)t.get((size_t)B * g.nchunk * 64 * sizeof(float));
+  for (int i = 0; i < 3; ++i) {
+    const int r = launch_groupnorm(g, dtype, s);
+    if (r) return r;
+  }
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  (void)hipEventRecord(e0, s);
+  for (int i = 0; i < iters; ++i) (void)launch_groupnorm(g, dtype, s);
+  (void)hipEventRecord(e1, s);
+  (void)hipEventSynchronize(e1);
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  *us_per_launch = 1e3f * ms / iters;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return 0;
+}
+
+// The fused evaluation tail (ldmseg_vae_decode_panoptic) on a given 4L decoder output x4 [B,C,H4,W4] f32 NCHW: packs it to
+// NHWC `dtype` and runs the resample + scan / filter / remap kernels.  volume (optional) receives the resampled logits
+// [C][h_b * w_b] of every image back to back (image b at C * offsets[b]) so that the interpolation chain itself can be
+// compared with F.interpolate o crop o F.interpolate.
+int ldmseg_op_panoptic_from_decoder(const float* x4, int B, int C, int H4, int W4, int dtype, int in_h, int in_w,
+                                    const int32_t* boxes, const int32_t* sizes, const int64_t* offsets, int threshold_output,
+                                    int threshold_mode, float mask_th, int count_th, double overlap_th, int64_t ignore_label,
+                                    int32_t* labels, int32_t* panoptic, uint8_t* keep, int32_t* counts, int32_t* mask_counts,
+                                    float* volume, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  Temp t;
+  void* xp = t.get((size_t)B * H4 * W4 * C * es(dtype));
+  if (!xp) return -3;
+  if (launch_pack_nchw(x4, xp, B, C, H4 * W4, C, 1.f, 0.f, dtype, s)) return -3;
+  return launch_panoptic_from_decoder(xp, B, H4, W4, C, dtype, in_h, in_w, boxes, sizes, offsets, threshold_output,
+                                      threshold_mode, mask_th, count_th, overlap_th, ignore_label, labels, panoptic, keep, counts,
+                                      mask_counts, s, volume);
+}
+
 int ldmseg_op_layernorm(const float* x, const float* gamma, const float* beta, int M, int C, float eps, int silu, int dtype,
                         float* out, void* stream) {
   hipStream_t s = (hipStream_t)stream;

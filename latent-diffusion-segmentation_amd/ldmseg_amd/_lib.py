@@ -66,6 +66,8 @@ SIGNATURES = {
     "ldmseg_vae_image_destroy": (None, [_vp]),
     "ldmseg_vae_image_num_params": (_i64, [_vp]),
     "ldmseg_vae_image_encode": (_i, [_vp, _vp, _f, _f, _i, _i, _i, _vp, _vp]),
+    "ldmseg_vae_decode_panoptic": (_i, [_vp, _vp, _f, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _f, _i, _d, _i64, _vp, _vp, _vp, _vp, _vp,
+                                        _vp]),
     "ldmseg_panoptic_postprocess": (_i, [_vp, _i, _i, _i, _i, _i, _i, _f, _i, _d, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ldmseg_bit_encode": (_i, [_vp, _i, _i, _i, _i64, _f, _f, _f, _vp, _vp, _vp]),
     "ldmseg_bit_decode": (_i, [_vp, _i, _i, _i, _vp, _vp]),
@@ -91,6 +93,9 @@ SIGNATURES = {
     "ldmseg_bench_igemm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
                                 C.POINTER(C.c_float), _vp]),
     "ldmseg_bench_attention": (_i, [_vp, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_float), _vp]),
+    "ldmseg_op_panoptic_from_decoder": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _f, _i, _d, _i64, _vp, _vp, _vp,
+                                             _vp, _vp, _vp, _vp]),
+    "ldmseg_bench_groupnorm": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_float), _vp]),
     "ldmseg_igemm_last_kernel": (_i, [C.c_char_p, _i]),
     "ldmseg_op_fastdiv": (_i, [_vp, _i, _i, _vp, _vp]),
     "ldmseg_igemm_log": (_i, [_i]),

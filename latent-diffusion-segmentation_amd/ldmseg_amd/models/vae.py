@@ -158,6 +158,47 @@ class GeneralVAESeg(object):
                        "ldmseg_vae_decode_argmax")
         return (ids, prob) if return_prob else ids
 
+    def decode_panoptic(self, z: torch.Tensor, in_size, out_sizes, crop_boxes=None, z_scale: float = 1.0,
+                        threshold_output: bool = True, threshold_mode: str = "max", mask_th: float = 0.5,
+                        count_th: int = 512, overlap_th: float = 0.5, ignore_label: int = 0, return_stats: bool = False):
+        """The evaluation tail of `compute_pq` (trainers_ldm_cond.py:1243-1313) fused behind the decoder: decode ->
+        bilinear x2 -> bilinear to `in_size` (H, W) -> crop to `crop_boxes[b]` = (y0, x0, height, width) -> bilinear to
+        `out_sizes[b]` = (h, w) -> argmax / thresholds / segment filtering, without the [B,128,H,W] logits.
+        Returns a list of (panoptic [h,w] int32 tensor on the GPU (label + 1, 0 = void), kept label list)."""
+        import numpy as np
+        z = _lib.require_cuda_f32(z, "z")
+        if threshold_mode not in ("max", "topk_diff"):
+            raise ValueError(f"unknown threshold_mode {threshold_mode!r}")
+        B, _, L, _ = z.shape
+        Cn = self.out_channels
+        sizes = np.ascontiguousarray(np.asarray(out_sizes, dtype=np.int32).reshape(B, 2))
+        boxes = None if crop_boxes is None else np.ascontiguousarray(np.asarray(crop_boxes, dtype=np.int32).reshape(B, 4))
+        npix = sizes[:, 0].astype(np.int64) * sizes[:, 1].astype(np.int64)
+        offs = np.ascontiguousarray(np.concatenate([[0], np.cumsum(npix)[:-1]]).astype(np.int64))
+        total = int(npix.sum())
+        dev = z.device
+        labels = torch.empty(total, dtype=torch.int32, device=dev)
+        pan = torch.empty(total, dtype=torch.int32, device=dev)
+        keep = torch.empty(B, Cn, dtype=torch.uint8, device=dev)
+        counts = torch.empty(B, Cn, dtype=torch.int32, device=dev)
+        mcounts = torch.empty(B, Cn, dtype=torch.int32, device=dev)
+        vp = lambda a: None if a is None else C.c_void_p(a.ctypes.data)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().ldmseg_vae_decode_panoptic(
+                self._h, _lib.ptr(z), float(z_scale), B, L, int(in_size[0]), int(in_size[1]), vp(boxes), vp(sizes), vp(offs),
+                int(bool(threshold_output)), 1 if threshold_mode == "topk_diff" else 0, float(mask_th), int(count_th),
+                float(overlap_th), int(ignore_label), _lib.ptr(labels), _lib.ptr(pan), _lib.ptr(keep), _lib.ptr(counts),
+                _lib.ptr(mcounts), _lib.stream_ptr(dev)), "ldmseg_vae_decode_panoptic")
+        keep_h = keep.cpu()
+        out = []
+        for b in range(B):
+            o, n = int(offs[b]), int(npix[b])
+            out.append((pan[o:o + n].view(int(sizes[b, 0]), int(sizes[b, 1])), torch.nonzero(keep_h[b]).flatten().tolist()))
+        if return_stats:
+            lab = [labels[int(offs[b]):int(offs[b]) + int(npix[b])].view(int(sizes[b, 0]), int(sizes[b, 1])) for b in range(B)]
+            return out, {"labels": lab, "counts": counts, "mask_counts": mcounts, "keep": keep}
+        return out
+
     def forward(self, sample, sample_posterior: bool = True, return_dict: bool = True,
                 generator: Optional[torch.Generator] = None, rgb_sample=None, valid_mask=None):
         if rgb_sample is not None:

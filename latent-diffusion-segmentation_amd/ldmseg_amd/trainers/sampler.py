@@ -268,16 +268,32 @@ class TrainerDiffusion(object):
         x0, x1 = int(co[:, 1].min()), int(co[:, 1].max())
         return prediction[:, y0:y1 + 1, x0:x1 + 1]
 
+    @staticmethod
+    def padding_boxes(padding_masks: torch.Tensor):
+        """The crop boxes of `crop_padding` for a whole batch, one D2H copy: [B,4] int32 numpy (y0, x0, height, width)."""
+        m = padding_masks != 0
+        rows, cols = m.any(dim=2), m.any(dim=1)                                   # [B,H], [B,W]
+        if not bool(rows.any(dim=1).all()):
+            raise ValueError("a padding mask without a single valid pixel")        # (the reference's .min() raises too)
+        H, W = rows.shape[1], cols.shape[1]
+        y0 = rows.int().argmax(dim=1)
+        y1 = H - 1 - rows.flip(1).int().argmax(dim=1)
+        x0 = cols.int().argmax(dim=1)
+        x1 = W - 1 - cols.flip(1).int().argmax(dim=1)
+        return torch.stack([y0, x0, y1 - y0 + 1, x1 - x0 + 1], dim=1).to(torch.int32).cpu().numpy()
+
     @torch.no_grad()
     def predict_panoptic(self, rgb_images: torch.Tensor, im_sizes, padding_masks: Optional[torch.Tensor] = None,
                          num_inference_steps: int = 50, guidance_scale: float = 7.5, seed: Optional[int] = None,
                          threshold_output: bool = True, threshold_mode: str = "max", scheduler=None, rgb_size: Optional[int] = None,
                          mask_th: float = 0.5, count_th: int = 512, overlap_th: float = 0.5, ignore_label: int = 0,
-                         return_intermediates: bool = False):
+                         return_intermediates: bool = False, fused: bool = True):
         """One batch of `compute_pq` (:1218-1313): RGB images [B,3,S,S] in [0,1] on the GPU -> `processed_results`
         (per image {"panoptic_seg": (panoptic map at the original size (h, w), segments_info)}).
-        Pixels -> image-VAE latents -> DDIM sampling -> seg-VAE logits -> bilinear to the input size -> crop the padding
-        -> bilinear to (h, w) -> argmax / thresholds / segment filtering on the GPU (ldmseg_panoptic_postprocess)."""
+        Pixels -> image-VAE latents -> DDIM sampling -> seg-VAE decoder -> [bilinear x2 -> bilinear to the input size ->
+        crop the padding -> bilinear to (h, w) -> argmax / thresholds / segment filtering].  The bracket runs as ONE fused
+        tail behind the decoder (`ldmseg_vae_decode_panoptic`: no [B,128,H,W] logits, no per-image torch interpolation);
+        `fused=False` (and `return_intermediates`) materialises the logits and walks the reference's steps one by one."""
         import torch.nn.functional as F
         if self.vae_image is None:
             raise ValueError("predict_panoptic needs the image VAE (TrainerDiffusion(..., vae_image=...))")
@@ -290,6 +306,15 @@ class TrainerDiffusion(object):
                                             scaling_factor=self.vae_image.scaling_factor, resize=rgb_size)
         latents = self.sample([""] * B, num_inference_steps, guidance_scale, seed, rgb_latents=rgb_latents,
                               scheduler=scheduler, disable_progress_bar=True)
+        sizes = [(int(s[0]), int(s[1])) for s in im_sizes]
+        if fused and not return_intermediates:
+            boxes = self.padding_boxes(padding_masks) if padding_masks is not None else None
+            outs = self.vae_semseg.decode_panoptic(
+                latents, (rgb_images.shape[-2], rgb_images.shape[-1]), sizes, boxes, z_scale=1.0 / self.vae_semseg.scaling_factor,
+                threshold_output=threshold_output, threshold_mode=threshold_mode, mask_th=mask_th, count_th=count_th,
+                overlap_th=overlap_th, ignore_label=ignore_label)
+            return [{"panoptic_seg": (pan, [{"id": int(c) + 1, "category_id": 1, "isthing": True} for c in kept])}
+                    for pan, kept in outs]
         logits = self.decode_latents(latents, return_logits=True)
         logits = F.interpolate(logits, size=(rgb_images.shape[-2], rgb_images.shape[-1]), mode="bilinear",
                                align_corners=False)                                           # :1252-1257
@@ -298,7 +323,7 @@ class TrainerDiffusion(object):
             m = logits[i]
             if padding_masks is not None:
                 m = self.crop_padding(m, padding_masks[i])                                    # :1263
-            h, w = int(im_sizes[i][0]), int(im_sizes[i][1])
+            h, w = sizes[i]
             m = F.interpolate(m[None].float(), size=(h, w), mode="bilinear", align_corners=False)   # :1266-1271
             results += self.postprocess_panoptic(m.contiguous(), threshold_output=threshold_output,
                                                  threshold_mode=threshold_mode, mask_th=mask_th, count_th=count_th,

@@ -118,3 +118,54 @@ def test_cross_rank_gather_gloo_world2():
     assert r["num_predictions"] == 4                                       # rank 1's images arrived
     # TP = 4 (IoUs 1, 1, 1, 2/3), FP = 1, FN = 0
     assert abs(r["SQ"] - 100 * (3 + 2 / 3) / 4) < 1e-9 and abs(r["RQ"] - 100 * 4 / 4.5) < 1e-9
+
+
+def test_eval_entry_batches_and_compute_pq_wiring(tmp_path, sched_kw):
+    """Host logic of the evaluation entry without a GPU: tools/main_ldm_eval.py::batches (PIL resize, meta, padding masks)
+    feeding TrainerDiffusion.compute_pq -> PanopticEvaluatorAgnostic with the model call replaced by a stand-in that
+    returns the ground truth - file names / image ids / sizes must arrive intact, and the `max_iter` quirk of the
+    reference loop (trainers_ldm_cond.py:1332: the check sits after the batch and uses `>`) must hold."""
+    import importlib.util
+    from PIL import Image
+    from conftest import ROOT
+    from ldmseg_amd.schedulers import DDIMNoiseScheduler
+    from ldmseg_amd.trainers import TrainerDiffusion
+    spec = importlib.util.spec_from_file_location("main_ldm_eval", os.path.join(ROOT, "tools", "main_ldm_eval.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    sizes = [(40, 60), (64, 48), (50, 50), (33, 70), (20, 20)]
+    g = np.random.RandomState(0)
+    gts = {}
+    for i, (h, w) in enumerate(sizes):
+        Image.fromarray(g.randint(0, 255, (h, w, 3)).astype(np.uint8)).save(tmp_path / f"im{i}.png")
+        gt = np.zeros((h, w), np.int64); gt[: h // 2] = 11 + i; gt[h // 2:] = 500 + i
+        gts[f"im{i}"] = gt
+    files = sorted(str(p) for p in tmp_path.glob("*.png"))
+    got = list(mod.batches(files, 32, 2, None))
+    assert [b["image"].shape for b in got] == [(2, 3, 32, 32), (2, 3, 32, 32), (1, 3, 32, 32)]
+    assert all(b["mask"].dtype == torch.bool and bool(b["mask"].all()) and b["mask"].shape == (len(b["meta"]), 32, 32) for b in got)
+    assert [m["im_size"] for b in got for m in b["meta"]] == sizes and got[1]["meta"][0]["image_id"] == "im2"
+    assert float(got[0]["image"].min()) >= 0.0 and float(got[0]["image"].max()) <= 1.0
+    assert TrainerDiffusion.padding_boxes(got[0]["mask"]).tolist() == [[0, 0, 32, 32], [0, 0, 32, 32]]
+    m = torch.zeros(2, 8, 10, dtype=torch.bool); m[0, 2:5, 3:9] = True; m[1, 7, 0] = True
+    assert TrainerDiffusion.padding_boxes(m).tolist() == [[2, 3, 3, 6], [7, 0, 1, 1]]
+    assert tuple(TrainerDiffusion.crop_padding(torch.zeros(4, 8, 10), m[0]).shape) == (4, 3, 6)
+
+    tr = TrainerDiffusion.__new__(TrainerDiffusion)
+    tr.noise_scheduler = DDIMNoiseScheduler(**sched_kw)
+    tr.device = torch.device("cpu")
+    seen = []
+
+    def fake_predict(rgb, im_sizes, masks, *a, **kw):
+        seen.append((tuple(rgb.shape), [tuple(s) for s in im_sizes], None if masks is None else tuple(masks.shape)))
+        k = len(seen) - 1
+        return [pred_out(gts[f"im{2 * k + j}"]) for j in range(rgb.shape[0])]
+    tr.predict_panoptic = fake_predict
+    ev = PanopticEvaluatorAgnostic(gt_maps=gts, gt_annotations=[ann(gts[f"im{i}"], f"im{i}") for i in range(5)])
+    res = tr.compute_pq(mod.batches(files, 32, 2, None), ev, num_inference_steps=5, seed=1, max_iter=0)["panoptic_seg"]
+    assert len(seen) == 2 and seen[0] == ((2, 3, 32, 32), sizes[:2], (2, 32, 32))      # batches 0 and 1, then the break
+    assert res["num_predictions"] == 4 and abs(res["PQ"] - 100.0) < 1e-9
+    assert tr.noise_scheduler.timesteps.tolist() == [999, 799, 599, 399, 199]
+    seen.clear()
+    res = tr.compute_pq(mod.batches(files, 32, 2, None), ev, num_inference_steps=5, seed=1)["panoptic_seg"]
+    assert res["num_predictions"] == 5

@@ -53,6 +53,24 @@ def igemm(case, dt="bf16", iters=20, B=8):
     return us.value, fl
 
 
+def gn(B, Cc, C2, HW, dt="bf16", iters=30, variant=0):
+    ga = torch.ones(Cc + C2, device="cuda")
+    be = torch.zeros(Cc + C2, device="cuda")
+    us = C.c_float()
+    L.ldmseg_debug_set(8, variant)
+    _lib.check(L.ldmseg_bench_groupnorm(P(ga), P(be), B, Cc, C2, HW, 1, DT[dt], iters, C.byref(us), None), "bench_groupnorm")
+    L.ldmseg_debug_set(8, 0)
+    byts = 2.0 * B * HW * (Cc + C2) * (2 if dt == "bf16" else 4)
+    print(f"groupnorm B={B} C={Cc}+{C2} HW={HW} {dt} variant={variant}: {us.value:8.1f} us  {byts / us.value / 1e6:6.2f} TB/s (1 read + 1 write)")
+    return us.value
+
+
+# the GroupNorm launch shapes of a B=8, L=64 forward: (C, C2, HW, launches per forward)
+GN_SHAPES = [(320, 0, 4096, 13), (320, 320, 4096, 2), (640, 320, 4096, 1), (320, 0, 1024, 1), (640, 0, 1024, 8), (640, 640, 1024, 1),
+             (640, 320, 1024, 1), (1280, 640, 1024, 1), (640, 0, 256, 1), (1280, 0, 256, 8), (1280, 1280, 256, 2), (1280, 640, 256, 1),
+             (1280, 0, 64, 11), (1280, 1280, 64, 3)]
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "attn"
     dt = os.environ.get("DT", "bf16")
@@ -62,6 +80,13 @@ if __name__ == "__main__":
             shapes = [(int(os.environ.get("B", 8)), int(sys.argv[2]), int(sys.argv[3]))]
         for s in shapes:
             attn(*s, dt=dt)
+    elif what == "gn":
+        Bq = int(os.environ.get("B", 8))
+        for variant in [int(v) for v in os.environ.get("VARIANTS", "0").split(",")]:
+            tot = 0.0
+            for (c, c2, hw, n) in GN_SHAPES:
+                tot += n * gn(Bq, c, c2, hw, dt=dt, variant=variant)
+            print(f"variant {variant}: {tot:.1f} us per forward over {sum(s[3] for s in GN_SHAPES)} norms")
     elif what == "igemm1":            # one shape of the list (PMC passes, ablations): kbench.py igemm1 <index> [ln]
         from test_igemm_shapes_gpu import SHAPES
         if os.environ.get("DBG"):

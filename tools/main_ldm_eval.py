@@ -63,7 +63,9 @@ def batches(files, size, batch, panoptic_dir):
             t, (h, w) = load_rgb(f, size)
             imgs.append(t)
             meta.append({"image_file": f, "image_id": os.path.splitext(os.path.basename(f))[0], "im_size": (h, w)})
-        yield {"image": torch.stack(imgs), "mask": None, "meta": meta}
+        # CropResize with the crop_mode=None the reference hard-wires (pil_transforms.py:102) only resizes: nothing is padded,
+        # the padding mask of every sample is all ones (compute_pq crops to its bounding box = the whole image)
+        yield {"image": torch.stack(imgs), "mask": torch.ones(len(imgs), size, size, dtype=torch.bool), "meta": meta}
 
 
 def main():
