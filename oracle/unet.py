@@ -52,8 +52,14 @@ def attention(sd, p, x, ctx=None):
     q = q.view(B, N, HEADS, d).transpose(1, 2)
     k = k.view(B, -1, HEADS, d).transpose(1, 2)
     v = v.view(B, -1, HEADS, d).transpose(1, 2)
-    s = torch.softmax((q @ k.transpose(-1, -2)) * (d ** -0.5), dim=-1)
-    o = (s @ v).transpose(1, 2).reshape(B, N, C)
+    # (query rows are independent: long sequences - 16384 tokens at 1024x1024 - go through in chunks so that the score
+    # matrix stays near 1 GB; the arithmetic per row is unchanged)
+    chunk = N if N <= 4096 else 2048
+    outs = []
+    for q0 in range(0, N, chunk):
+        s = torch.softmax((q[:, :, q0:q0 + chunk] @ k.transpose(-1, -2)) * (d ** -0.5), dim=-1)
+        outs.append(s @ v)
+    o = (outs[0] if len(outs) == 1 else torch.cat(outs, dim=2)).transpose(1, 2).reshape(B, N, C)
     return F.linear(o, sd[p + "to_out.0.weight"], sd[p + "to_out.0.bias"])
 
 

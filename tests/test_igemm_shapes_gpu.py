@@ -1,6 +1,7 @@
-"""Parity of the SHIPPED implicit-GEMM instantiations at the real UNet launch shapes (B = 8, 512x512 images).
+"""Parity of the SHIPPED implicit-GEMM instantiations at the real UNet launch shapes of the three single-GPU
+configurations of BASELINE.json: configs[1] (B = 8, L = 64), configs[3] (B = 16, L = 64), configs[4] (B = 4, L = 128).
 
-Every distinct conv / Linear / GEGLU launch shape of a batch-8, L = 64 UNet forward is launched through
+Every distinct conv / Linear / GEGLU launch shape of a UNet forward of each configuration is launched through
 ``ldmseg_op_igemm`` - the engine's own launch path: NHWC operands, the engine's split-K plan, the row-major store /
 GEGLU epilogues, residual and time-embedding bias rows - in bf16 and fp32 under the shipped tile policy, and compared
 with the torch-CPU op the reference executes there (F.conv2d / F.linear / GEGLU of diffusers 0.16.1).
@@ -16,8 +17,11 @@ from conftest import rel_err
 pytestmark = pytest.mark.gpu
 
 F32, BF16 = 0, 1
-B = 8
-SEEN = {F32: set(), BF16: set()}
+# (batch, latent size): the measured launch table (csrc/igemm_tuned.inc) has entries - instantiation x K-slice count - for
+# exactly these three; every other shape goes through the rules that the same lists exercise
+CONFIGS = [(8, 64), (16, 64), (4, 128)]
+CFG_IDS = [f"b{b}l{l}" for b, l in CONFIGS]
+SEEN = {(c, dt): set() for c in CONFIGS for dt in (F32, BF16)}
 
 
 @pytest.fixture(scope="module")
@@ -40,7 +44,7 @@ def P(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
-# (H, Ci, Ci2, Co, k, stride, up, geglu, resid, rowbias)  -  H = input side; all at batch 8
+# (H, Ci, Ci2, Co, k, stride, up, geglu, resid, rowbias)  -  H = input side AT L = 64 (scaled by L / 64 for the other latent size)
 SHAPES = [
     # ---- 64x64 maps (M = 32768)
     (64, 320, 0, 320, 3, 1, 0, 0, 0, 1),      # resnet conv1 (+ time-embedding row)
@@ -102,10 +106,13 @@ SHAPES = [
 
 
 @pytest.mark.parametrize("dt", [BF16, F32])
+@pytest.mark.parametrize("cfg", CONFIGS, ids=CFG_IDS)
 @pytest.mark.parametrize("case", SHAPES)
-def test_unet_layer_shape_vs_oracle(L, dt, case):
+def test_unet_layer_shape_vs_oracle(L, dt, cfg, case):
     H, Ci, Ci2, Co, k, stride, up, geglu, use_res, use_rb = case
-    torch.set_num_threads(32)
+    B, lat = cfg
+    H = H * lat // 64
+    torch.set_num_threads(64)
     g = torch.Generator().manual_seed(hash(case) & 0xffff)
     ct = Ci + Ci2
     x = torch.randn(B, Ci, H, H, generator=g)
@@ -133,25 +140,27 @@ def test_unet_layer_shape_vs_oracle(L, dt, case):
     assert r == 0, L.lib().ldmseg_last_error()
     torch.cuda.synchronize()
     name = L.igemm_last_kernel()
-    SEEN[dt].add(name.split(" ")[0])
+    SEEN[(cfg, dt)].add(name.split(" ")[0])
     # bf16: operands rounded identically, the difference is accumulation order + the bf16 rounding of the stored output
-    assert rel_err(out, ref) < (8e-3 if dt == BF16 else 1e-4), (case, name)
+    assert rel_err(out, ref) < (8e-3 if dt == BF16 else 1e-4), (cfg, case, name)
 
 
-LN_SHAPES = [   # (M, K = C, N, geglu): norm1 -> q|k|v and norm3 -> ff.net.0.proj of every transformer level at B = 8
+LN_SHAPES = [   # (M at B = 8 / L = 64, K = C, N, geglu): norm1 -> q|k|v and norm3 -> ff.net.0.proj of every transformer level
     (32768, 320, 960, 0), (32768, 320, 2560, 1), (8192, 640, 1920, 0), (8192, 640, 5120, 1),
     (2048, 1280, 3840, 0), (2048, 1280, 10240, 1), (512, 1280, 3840, 0), (512, 1280, 10240, 1),
 ]
 
 
 @pytest.mark.parametrize("dt", [BF16, F32])
+@pytest.mark.parametrize("cfg", CONFIGS, ids=CFG_IDS)
 @pytest.mark.parametrize("M,K,N,geglu", LN_SHAPES)
-def test_unet_layernorm_folded_gemm_vs_oracle(L, dt, M, K, N, geglu):
+def test_unet_layernorm_folded_gemm_vs_oracle(L, dt, cfg, M, K, N, geglu):
     """LayerNorm -> Linear / GEGLU of the transformer blocks as the engine runs them: one statistics pass, then the GEMM
     on the un-normalised tokens with gamma folded into the weights and rstd*(acc - mean*c1) + c2 in the epilogue (its own
     template instantiations, ',ln').  Reference: F.layer_norm + F.linear (+ GEGLU); the tokens carry a large common offset
     (mean 3, std 1.5) so the mean cancellation of the epilogue is exercised."""
-    torch.set_num_threads(32)
+    torch.set_num_threads(64)
+    M = M * cfg[0] * cfg[1] * cfg[1] // (8 * 64 * 64)
     g = torch.Generator().manual_seed(M + N)
     x = torch.randn(M, K, generator=g) * 1.5 + 3.0
     gamma = 1 + 0.2 * torch.randn(K, generator=g)
@@ -169,35 +178,40 @@ def test_unet_layernorm_folded_gemm_vs_oracle(L, dt, M, K, N, geglu):
     torch.cuda.synchronize()
     name = L.igemm_last_kernel()
     assert ",ln" in name
-    SEEN[dt].add(name.split(" ")[0])
+    SEEN[(cfg, dt)].add(name.split(" ")[0])
     # bf16: gamma*W and the output are rounded to bf16 (the unfolded form rounds LN(x) and W instead)
     assert rel_err(out, y) < (1.5e-2 if dt == BF16 else 1e-4), name
 
 
 @pytest.mark.parametrize("dt", [BF16, F32])
-def test_conv_out_shape_vs_oracle(L, dt):
-    """conv_out: 320 -> 4 channels at 64x64, written straight to fp32 NCHW (EPI_NCHW_F32, the narrow-N tile)."""
+@pytest.mark.parametrize("cfg", CONFIGS, ids=CFG_IDS)
+def test_conv_out_shape_vs_oracle(L, dt, cfg):
+    """conv_out: 320 -> 4 channels at the full latent resolution, written straight to fp32 NCHW (EPI_NCHW_F32, the narrow-N tile)."""
+    B, lat = cfg
     g = torch.Generator().manual_seed(4)
-    x = torch.randn(B, 320, 64, 64, generator=g)
+    x = torch.randn(B, 320, lat, lat, generator=g)
     w = torch.randn(4, 320, 3, 3, generator=g) / 2880 ** 0.5
     b = torch.randn(4, generator=g)
     xr, wr = (bf16_round(x), bf16_round(w)) if dt == BF16 else (x, w)
     ref = F.conv2d(xr, wr, b, padding=1)
     out = torch.empty(ref.shape, device="cuda")
     dx, dw, db = dev(x), dev(w), dev(b)
-    assert L.lib().ldmseg_op_conv2d(P(dx), None, P(dw), P(db), B, 320, 0, 64, 64, 4, 3, 1, 0, dt, P(out), None) == 0
+    assert L.lib().ldmseg_op_conv2d(P(dx), None, P(dw), P(db), B, 320, 0, lat, lat, 4, 3, 1, 0, dt, P(out), None) == 0
     torch.cuda.synchronize()
-    SEEN[dt].add(L.igemm_last_kernel().split(" ")[0])
+    SEEN[(cfg, dt)].add(L.igemm_last_kernel().split(" ")[0])
     assert rel_err(out, ref) < (1e-3 if dt == BF16 else 1e-4)
 
 
 @pytest.mark.parametrize("mode,dt", [("bf16", BF16), ("fp32", F32)])
-def test_every_forward_instantiation_is_oracle_tested(L, unet_sd, mode, dt):
-    """Run a batch-8, L = 64 forward (BASELINE configs[1]) with the dispatch log on: every igemm instantiation it
-    launches must be one that a per-layer test above has just compared with the oracle."""
+@pytest.mark.parametrize("cfg", CONFIGS, ids=CFG_IDS)
+def test_every_forward_instantiation_is_oracle_tested(L, unet_sd, cfg, mode, dt):
+    """Run a forward of the configuration (BASELINE configs[1] / [3] / [4]) with the dispatch log on: every igemm
+    instantiation - tile shape, wave layout, ring depth, K-sliced or not - it launches must be one that a per-layer test
+    above has just compared with the oracle AT THIS CONFIGURATION'S shapes."""
     from ldmseg_amd.models import UNet
+    B, lat = cfg
     u = UNet(unet_sd, in_channels=12, device="cuda:0", compute_dtype=mode)
-    x = torch.randn(B, 12, 64, 64, generator=torch.Generator().manual_seed(1)).cuda()
+    x = torch.randn(B, 12, lat, lat, generator=torch.Generator().manual_seed(1)).cuda()
     L.igemm_log(True)
     try:
         y = u(x, 499).sample
@@ -207,5 +221,6 @@ def test_every_forward_instantiation_is_oracle_tested(L, unet_sd, mode, dt):
         L.igemm_log(False)
     assert torch.isfinite(y).all()
     assert len(used) >= 4, used
-    missing = used - SEEN[dt]
-    assert not missing, f"forward instantiations without a per-layer oracle test: {sorted(missing)}; tested: {sorted(SEEN[dt])}"
+    missing = used - SEEN[(cfg, dt)]
+    assert not missing, (f"{cfg}: forward instantiations without a per-layer oracle test: {sorted(missing)}; "
+                         f"tested: {sorted(SEEN[(cfg, dt)])}")
