@@ -37,6 +37,23 @@ def test_two_ranks_over_gloo_share_the_device_and_say_so():
     if ndev < 2:
         assert "NOT a multi-GPU measurement" in out["note"]
     assert out["value"] > 0 and out["images_per_s_50step_ddim_incl_decode"] > 0
+    # the decomposition a multi-GPU run is read by: every rank's own step time and the one collective on its own
+    assert len(out["per_rank_ms_per_step"]) == 2 and max(out["per_rank_ms_per_step"]) == pytest.approx(out["ms_per_step"], rel=1e-6)
+    assert out["allgather_latents"]["bytes_per_rank"] == 8 * 4 * 64 * 64 * 4 and out["allgather_latents"]["us"] > 0
+
+
+def test_two_ranks_over_rccl_when_two_devices_are_visible():
+    """The measured configuration - one rank per GPU, RCCL all-gather of the latents over xGMI - whenever the box has at
+    least two devices (the driver's GPU-test box has one: skipped there; the 8-GPU scaling run is the driver's)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible devices")
+    r = run_bench(2, {"LDMSEG_BENCH_BACKEND": "nccl"}, 29543)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 2 and out["config"]["backend"] == "nccl" and not out["config"]["ranks_share_device"]
+    assert out["config"]["global_batch"] == 16 and len(out["per_rank_ms_per_step"]) == 2
+    assert out["allgather_latents"]["backend"] == "nccl" and out["allgather_latents"]["us"] > 0
+    assert out["value"] > 0 and "note" not in out
 
 
 def test_rccl_refuses_more_ranks_than_devices():
