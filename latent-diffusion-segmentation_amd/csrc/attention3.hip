@@ -57,7 +57,7 @@ __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
 }
 
-template <int D> struct A3Cfg {
+template <int D, int NWV = 4> struct A3Cfg {
   static constexpr int DCH = D / 8;                  // data planes per tile and operand (16-byte chunks per row)
   static constexpr int KG = (D + 1 + 31) / 32;       // 32-wide k-groups of the QK^T contraction (incl. the -m column)
   static constexpr int DF = (D + 1 + 15) / 16;       // 16-row fragments of O^T (incl. the row-sum row D)
@@ -65,16 +65,17 @@ template <int D> struct A3Cfg {
   static constexpr int KPS = 1024, VPS = 1152;       // plane strides (bytes)
   static constexpr int KBYTES = NPL * KPS, VBYTES = NPL * VPS;
   static constexpr int STAGE = KBYTES + VBYTES;
-  static constexpr int VSH = (4 - DCH % 4) % 4;      // V planes start at wave VSH's successor... balances the DMA instructions over the 4 waves
-  static constexpr int JMAX = (DCH + 3) / 4;
+  static constexpr int VSH = (NWV - DCH % NWV) % NWV; // V planes start at wave VSH's successor... balances the DMA instructions over the waves
+  static constexpr int JMAX = (DCH + NWV - 1) / NWV;
   static_assert(D % 8 == 0 && D % 32 != 0, "needs a spare contraction column");
 };
 
 // NST LDS stages; the DMA stream runs NST-1 key tiles ahead of the compute stream
-template <int D, int QF, int WPS, int NST, bool PIPE>
-__global__ __launch_bounds__(256, WPS) void attn3_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int N, int C,
+template <int D, int QF, int WPS, int NST, bool PIPE, int LAZY, int NWV>
+__global__ __launch_bounds__(64 * NWV, WPS) void attn3_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int N, int C,
                                                          int heads, float scale_log2e) {
-  using Cfg = A3Cfg<D>;
+  using Cfg = A3Cfg<D, NWV>;
+  static_assert(!PIPE, "the software-pipelined loop (QK^T of tile t+1 issued before the softmax of tile t; 248 VGPRs, measured 11 % slower) was removed in round 3");
   constexpr float THR = 6.0f;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(256, WPS) void attn3_kernel(const bf16_t* __restric
   const int lq = lane & 15, lg = lane >> 4;
 
   // XCD-aware: all query blocks of one (image, head) share an XCD's L2
-  const int nqb = (N + 64 * QF - 1) / (64 * QF);
+  const int nqb = (N + 16 * NWV * QF - 1) / (16 * NWV * QF);
   int wg;
   {
     const int nwg = gridDim.x, bid = blockIdx.x;
@@ -101,18 +102,18 @@ __global__ __launch_bounds__(256, WPS) void attn3_kernel(const bf16_t* __restric
 
   // ---- constant planes: chunk DCH of every key is [1, 0, 0, 0, 0, 0, 0, 0] in all stages, for K (the -m column) and V
   // (the row-sum row); the DMA never touches them
-  for (int i = tid; i < NST * 2 * BKV3; i += 256) {
+  for (int i = tid; i < NST * 2 * BKV3; i += 64 * NWV) {
     const int st = i / (2 * BKV3), rem = i - st * (2 * BKV3), which = rem / BKV3, key = rem - which * BKV3;
     unsigned char* p = smem + st * Cfg::STAGE + (which ? Cfg::KBYTES + Cfg::DCH * Cfg::VPS : Cfg::DCH * Cfg::KPS) + key * 16;
     *(uint4*)p = make_uint4(0x3f80u, 0u, 0u, 0u);
   }
 
-  // ---- DMA stream: K plane c = wave + 4j, V plane c = ((wave + VSH) & 3) + 4j; lane = key of the tile
+  // ---- DMA stream: K plane c = wave + NWV j, V plane c = ((wave + VSH) % NWV) + NWV j; lane = key of the tile
   const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)smem);
-  const int wv = (wave + Cfg::VSH) & 3;
+  const int wv = (wave + Cfg::VSH) % NWV;
   int my_cnt = 0;                                           // DMA instructions this wave issues per tile
 #pragma unroll
-  for (int j = 0; j < Cfg::JMAX; ++j) my_cnt += (wave + 4 * j < Cfg::DCH) + (wv + 4 * j < Cfg::DCH);
+  for (int j = 0; j < Cfg::JMAX; ++j) my_cnt += (wave + NWV * j < Cfg::DCH) + (wv + NWV * j < Cfg::DCH);
   my_cnt = __builtin_amdgcn_readfirstlane(my_cnt);
   auto issue_tile = [&](int t, int stage) __attribute__((always_inline)) {
     const int row = min(t * BKV3 + lane, N - 1);           // keys past N are clamped (finite data) and masked below
@@ -123,14 +124,16 @@ __global__ __launch_bounds__(256, WPS) void attn3_kernel(const bf16_t* __restric
     const unsigned vdst = __builtin_amdgcn_readfirstlane(lds0 + stage * Cfg::STAGE + Cfg::KBYTES + wv * Cfg::VPS);
     static_for_n<Cfg::JMAX>([&](auto jc) __attribute__((always_inline)) {
       constexpr int J = decltype(jc)::value;
-      if (wave + 4 * J < Cfg::DCH) glds16_off<J * 64>(kp, kdst + J * 4 * Cfg::KPS);
-      if (wv + 4 * J < Cfg::DCH) glds16_off<J * 64>(vp, vdst + J * 4 * Cfg::VPS);
+      if (wave + NWV * J < Cfg::DCH) glds16_off<J * NWV * 16>(kp, kdst + J * NWV * Cfg::KPS);
+      if (wv + NWV * J < Cfg::DCH) glds16_off<J * NWV * 16>(vp, vdst + J * NWV * Cfg::VPS);
     });
   };
   // wait until at most `ahead` tiles of this wave's DMA are still in flight (my_cnt in {2,3,5}: wave-uniform)
   auto wait_tiles_ahead = [&](int ahead) __attribute__((always_inline)) {
     if (ahead == 0) { wait_vm<0>(); return; }
-    if (my_cnt == 2) wait_vm<2>();
+    if (my_cnt == 0) return;
+    if (my_cnt == 1) wait_vm<1>();
+    else if (my_cnt == 2) wait_vm<2>();
     else if (my_cnt == 3) wait_vm<3>();
     else if (my_cnt == 4) wait_vm<4>();
     else if (my_cnt == 5) wait_vm<5>();
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(256, WPS) void attn3_kernel(const bf16_t* __restric
   });
 
   // ---- Q fragments (MFMA B operand): lane (q = lq, g = lg) holds chunk kg*4+g of its row, pre-scaled by d^-1/2 log2 e
-  const int q0 = qb * 64 * QF + wave * 16 * QF;
+  const int q0 = qb * 16 * NWV * QF + wave * 16 * QF;
   uint4 qf[QF][Cfg::KG];
 #pragma unroll
   for (int a = 0; a < QF; ++a) {
@@ -203,7 +206,7 @@ __global__ __launch_bounds__(256, WPS) void attn3_kernel(const bf16_t* __restric
   }
   // softmax numerators of tile T_ in place (SARR <- p), moving the folded maxima when a row outgrew them.  SNXT: scores of
   // the NEXT tile that were already computed against the old maxima (pipelined loop) and must move with them, or SARR.
-#define A3_SOFTMAX(SARR, SNXT, HAS_NXT, T_, RAGGED_)                                                            \
+#define A3_SOFTMAX(SARR, SNXT, HAS_NXT, T_, RAGGED_, CHECK_)                                                    \
   {                                                                                                             \
     if constexpr (RAGGED_) {                                                                                    \
       _Pragma("unroll") for (int a = 0; a < QF; ++a)                                                            \
@@ -211,6 +214,7 @@ __global__ __launch_bounds__(256, WPS) void attn3_kernel(const bf16_t* __restric
           _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                         \
             if ((T_) * BKV3 + 16 * f + 4 * lg + r >= N) SARR[a][f][r] = -INFINITY;                              \
     }                                                                                                           \
+    if constexpr (CHECK_) {                                                                                     \
     float tmax[QF];                                                                                             \
     bool need_any = ((T_) == 0);                                                                                \
     _Pragma("unroll") for (int a = 0; a < QF; ++a) {                                                            \
@@ -251,6 +255,7 @@ __global__ __launch_bounds__(256, WPS) void attn3_kernel(const bf16_t* __restric
         if (holds_m) qf[a][MKG].x = f32_bits(-mrow[a]) >> 16; /* column D of Q: bf16(-m); D+1.. stay zero */    \
       }                                                                                                         \
     }                                                                                                           \
+    }                                                                                                           \
     _Pragma("unroll") for (int a = 0; a < QF; ++a)                                                              \
       _Pragma("unroll") for (int f = 0; f < 4; ++f)                                                             \
         _Pragma("unroll") for (int r = 0; r < 4; ++r) SARR[a][f][r] = __builtin_amdgcn_exp2f(SARR[a][f][r]);    \
@@ -279,67 +284,68 @@ __global__ __launch_bounds__(256, WPS) void attn3_kernel(const bf16_t* __restric
   }
 
   f32x4 sA[QF][4];
-  if constexpr (!PIPE) {
+  // One key tile.  STAGE, RAGGED and CHECK are compile-time: the LDS offsets of every fragment read fold into immediates,
+  // the -inf masking of keys past N exists only in the instantiation the last, partial tile runs (as a run-time branch
+  // the compiler if-converts it into ~45 VALU instructions on every tile), and so does the row-maximum code.
+  auto tile = [&](int t, auto stage_c, auto ragged_c, auto check_c) __attribute__((always_inline)) {
+    constexpr int ST = decltype(stage_c)::value;
+    constexpr bool RAGGED = decltype(ragged_c)::value;
+    constexpr bool CHECK = decltype(check_c)::value;
+    if (t + NST - 1 < ntiles) issue_tile(t + NST - 1, (ST + NST - 1) % NST);
+    A3_QK(sA, ST)
+    A3_SOFTMAX(sA, sA, false, t, RAGGED, CHECK)
+    A3_PV(sA, ST)
+    // the next tile must have landed before anyone reads it; the one after may stay in flight
+    if (t + 1 < ntiles) wait_tiles_ahead((NST > 2 && t + 2 < ntiles) ? 1 : 0);
+    __syncthreads();
+  };
+  // All key tiles (the DMA prologue - tiles 0 .. NST-2 - is in flight).  PERIOD: the row maxima are looked at on tile 0, on
+  // every PERIOD-th tile and on the ragged tail only.  The folded maximum m only has to keep exp2(s - m) inside fp32 / bf16
+  // range - a score may exceed it by up to ~2^7 - and the relative accuracy of p does not depend on m, so between looks the
+  // scores are exponentiated against the m of the last look (max3 + the cross-lane reductions were 45 % of the VALU
+  // instructions of a tile: d = 40, N = 4096 at B = 8: 239 -> 220 us).  A row whose scores outgrew m by more than that between
+  // two looks shows up as a row sum >= 2^100 (inf included) and sends the whole workgroup through the exact pass below.
+  auto all_tiles = [&](auto period_c) __attribute__((always_inline)) {
+    constexpr int PERIOD = decltype(period_c)::value;
+    static_assert(PERIOD >= 1 && (PERIOD & (PERIOD - 1)) == 0, "power of two");
     // tiles in flight beyond tile 0 after the prologue: min(NST - 1, ntiles) - 1
     wait_tiles_ahead((NST > 2 && ntiles > 1) ? 1 : 0);
     __syncthreads();
-    // One key tile.  STAGE and RAGGED are compile-time: the LDS offsets of every fragment read fold into immediates,
-    // and the -inf masking of keys past N exists only in the instantiation the last, partial tile runs (as a run-time
-    // branch the compiler if-converts it into ~45 VALU instructions on every tile).
-    auto tile = [&](int t, auto stage_c, auto ragged_c) __attribute__((always_inline)) {
-      constexpr int ST = decltype(stage_c)::value;
-      constexpr bool RAGGED = decltype(ragged_c)::value;
-      if (t + NST - 1 < ntiles) issue_tile(t + NST - 1, (ST + NST - 1) % NST);
-      A3_QK(sA, ST)
-      A3_SOFTMAX(sA, sA, false, t, RAGGED)
-      A3_PV(sA, ST)
-      // the next tile must have landed before anyone reads it; the one after may stay in flight
-      if (t + 1 < ntiles) wait_tiles_ahead((NST > 2 && t + 2 < ntiles) ? 1 : 0);
-      __syncthreads();
-    };
     for (int t0 = 0; t0 < ntiles; t0 += NST) {
       static_for_n<NST>([&](auto sc) __attribute__((always_inline)) {
         const int t = t0 + decltype(sc)::value;
-        if (t < nfull) tile(t, sc, std::false_type{});
-        else if (t < ntiles) tile(t, sc, std::true_type{});
+        if (t < nfull) {
+          if (PERIOD == 1 || (t & (PERIOD - 1)) == 0) tile(t, sc, std::false_type{}, std::true_type{});
+          else tile(t, sc, std::false_type{}, std::false_type{});
+        } else if (t < ntiles) {
+          tile(t, sc, std::true_type{}, std::true_type{});
+        }
       });
     }
-  } else {
-    // Software-pipelined loop: iteration t issues the QK^T matrix products of tile t+1 BEFORE the softmax of tile t, so
-    // that every wave always has independent MFMA work (QK^T of t+1, then PV of t) next to its VALU work (softmax of t).
-    // In the plain loop a wave alternates between a pure-MFMA and a pure-VALU phase and the SIMD's two pipes only
-    // overlap across waves (measured: MFMA pipe 41 % busy, VALU 22 %, 38 % of the cycles neither).  K therefore runs
-    // two tiles ahead of the compute stream: NST = 4 stages, the DMA stream three tiles ahead.
-    static_assert(!PIPE || NST == 4, "the pipelined loop alternates two score arrays over a 4-stage ring");
-    f32x4 sB[QF][4];
-    wait_tiles_ahead(ntiles > 2 ? 1 : 0);       // tiles 0 and 1 landed (tile 2 may be in flight)
-    __syncthreads();
-    A3_QK(sA, 0)
-#define A3_PIPE_TILE(T_, ST, CUR, NXT, RAGGED_)                                                                 \
-  {                                                                                                             \
-    if ((T_) + 3 < ntiles) issue_tile((T_) + 3, ((ST) + 3) % 4);                                                \
-    const bool has_nxt = (T_) + 1 < ntiles;                                                                     \
-    if (has_nxt) A3_QK(NXT, ((ST) + 1) % 4)                                                                     \
-    A3_SOFTMAX(CUR, NXT, has_nxt, T_, RAGGED_)                                                                  \
-    A3_PV(CUR, ST)                                                                                              \
-    /* tile T_+2 (its K planes feed the next iteration) must have landed; T_+3 may stay in flight */            \
-    if ((T_) + 2 < ntiles) wait_tiles_ahead((T_) + 3 < ntiles ? 1 : 0);                                         \
-    __syncthreads();                                                                                            \
-  }
-#define A3_PIPE_STEP(T_, ST, CUR, NXT)                                     \
-  {                                                                        \
-    const int t_ = (T_);                                                   \
-    if (t_ < nfull) A3_PIPE_TILE(t_, ST, CUR, NXT, false)                  \
-    else if (t_ < ntiles) A3_PIPE_TILE(t_, ST, CUR, NXT, true)             \
-  }
-    for (int t0 = 0; t0 < ntiles; t0 += 4) {      // no lambdas here: the score arrays must stay in registers
-      A3_PIPE_STEP(t0 + 0, 0, sA, sB)
-      A3_PIPE_STEP(t0 + 1, 1, sB, sA)
-      A3_PIPE_STEP(t0 + 2, 2, sA, sB)
-      A3_PIPE_STEP(t0 + 3, 3, sB, sA)
+  };
+  all_tiles(std::integral_constant<int, LAZY>{});
+  if constexpr (LAZY > 1) {
+    bool bad = false;
+#pragma unroll
+    for (int a = 0; a < QF; ++a) {
+      // (an exponent test on the bits: this file is built with -fno-honor-nans, a float compare may be folded for NaN)
+      const unsigned lb = f32_bits(o[a][D / 16][(D % 16) % 4]);
+      bad |= (lg == (D % 16) / 4) && ((lb & 0x7f800000u) >= ((127u + 100u) << 23));
     }
-#undef A3_PIPE_STEP
-#undef A3_PIPE_TILE
+    if (__syncthreads_or(bad ? 1 : 0)) {            // rare: start over with the maxima tracked on every tile
+#pragma unroll
+      for (int a = 0; a < QF; ++a) {
+        mrow[a] = 0.f;
+        if (holds_m) qf[a][MKG].x = 0u;
+#pragma unroll
+        for (int d = 0; d < Cfg::DF; ++d) o[a][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      static_for_n<NST - 1>([&](auto jc) __attribute__((always_inline)) {
+        constexpr int J = decltype(jc)::value;
+        if (J < ntiles) issue_tile(J, J);
+      });
+      all_tiles(std::integral_constant<int, 1>{});
+    }
   }
 #undef A3_QK
 #undef A3_SOFTMAX
@@ -364,11 +370,11 @@ __global__ __launch_bounds__(256, WPS) void attn3_kernel(const bf16_t* __restric
   }
 }
 
-template <int D, int QF, int WPS, int NST, bool PIPE = false>
+template <int D, int QF, int WPS, int NST, bool PIPE = false, int LAZY = 1, int NWV = 4>
 int run3(const void* qkv, void* out, int B, int N, int C, int heads, hipStream_t s) {
-  using Cfg = A3Cfg<D>;
+  using Cfg = A3Cfg<D, NWV>;
   const size_t lds = (size_t)NST * Cfg::STAGE;
-  auto kern = attn3_kernel<D, QF, WPS, NST, PIPE>;
+  auto kern = attn3_kernel<D, QF, WPS, NST, PIPE, LAZY, NWV>;
   static bool attr_set[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
@@ -376,9 +382,9 @@ int run3(const void* qkv, void* out, int B, int N, int C, int heads, hipStream_t
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set[dev] = true;
   }
-  const int nqb = (N + 64 * QF - 1) / (64 * QF);
+  const int nqb = (N + 16 * NWV * QF - 1) / (16 * NWV * QF);
   const float scale_log2e = (1.0f / sqrtf((float)D)) * 1.4426950408889634f;
-  hipLaunchKernelGGL(kern, dim3(nqb * heads * B), dim3(256), lds, s, (const bf16_t*)qkv, (bf16_t*)out, N, C, heads, scale_log2e);
+  hipLaunchKernelGGL(kern, dim3(nqb * heads * B), dim3(64 * NWV), lds, s, (const bf16_t*)qkv, (bf16_t*)out, N, C, heads, scale_log2e);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
@@ -387,19 +393,31 @@ int run3(const void* qkv, void* out, int B, int N, int C, int heads, hipStream_t
 // bf16, head dim 40 or 80; returns -100 when the shape is not handled here (caller falls through to attention.hip)
 int launch_attention3(const void* qkv, void* out, int B, int N, int C, int heads, int variant, hipStream_t s) {
   const int d = C / heads;
-  // variant: 0 = shipped choice; 1, 4, 5 = alternatives kept for A/B measurements (tools/kbench.py)
+  // variant: 0 = shipped choice; the others are alternatives kept for A/B measurements and the parity tests
+  // (template arguments: head dim, query fragments per wave, waves per SIMD, ring stages, -, maxima look period, waves per workgroup)
   if (d == 40) {
     if (variant == 1) return run3<40, 1, 4, 3>(qkv, out, B, N, C, heads, s);
     if (variant == 4) return run3<40, 2, 3, 2>(qkv, out, B, N, C, heads, s);
     if (variant == 5) return run3<40, 2, 4, 3>(qkv, out, B, N, C, heads, s);
-    if (variant == 7) return run3<40, 2, 2, 4, true>(qkv, out, B, N, C, heads, s);   // software-pipelined loop: 248 VGPRs, measured 11 % slower
-    return run3<40, 2, 3, 3>(qkv, out, B, N, C, heads, s);
+    if (variant == 6) return run3<40, 2, 3, 3>(qkv, out, B, N, C, heads, s);                  // the round-2 kernel: 4 waves, maxima on every tile
+    if (variant == 8) return run3<40, 2, 4, 3, false, 1, 8>(qkv, out, B, N, C, heads, s);     // 8 waves, maxima on every tile
+    if (variant == 9) return run3<40, 2, 4, 3, false, 4, 8>(qkv, out, B, N, C, heads, s);
+    if (variant == 10) return run3<40, 2, 3, 3, false, 16, 4>(qkv, out, B, N, C, heads, s);
+    // 8-wave workgroups: 256 query rows share every K / V tile (half the LDS-DMA instructions per score: issuing one parks
+    // the wave for 60-185 cycles); short sequences keep the 4-wave form (too few workgroups otherwise)
+    if (variant == 0 && (long)B * heads * ((N + 255) / 256) >= 256) return run3<40, 2, 4, 3, false, 16, 8>(qkv, out, B, N, C, heads, s);
+    return run3<40, 2, 3, 3, false, 16, 4>(qkv, out, B, N, C, heads, s);
   }
   if (d == 80) {
     if (variant == 1) return run3<80, 1, 3, 2>(qkv, out, B, N, C, heads, s);
     if (variant == 4) return run3<80, 2, 3, 2>(qkv, out, B, N, C, heads, s);
     if (variant == 5) return run3<80, 1, 2, 3>(qkv, out, B, N, C, heads, s);
-    return run3<80, 2, 2, 3>(qkv, out, B, N, C, heads, s);
+    if (variant == 6) return run3<80, 2, 2, 3>(qkv, out, B, N, C, heads, s);                  // the round-2 kernel
+    if (variant == 8) return run3<80, 1, 4, 3, false, 16, 8>(qkv, out, B, N, C, heads, s);
+    if (variant == 9) return run3<80, 2, 2, 3, false, 16, 8>(qkv, out, B, N, C, heads, s);
+    if (variant == 10) return run3<80, 1, 3, 3, false, 16, 8>(qkv, out, B, N, C, heads, s);
+    if (variant == 0 && (long)B * heads * ((N + 255) / 256) >= 256) return run3<80, 2, 2, 3, false, 16, 8>(qkv, out, B, N, C, heads, s);
+    return run3<80, 2, 2, 3, false, 16, 4>(qkv, out, B, N, C, heads, s);
   }
   return -100;
 }

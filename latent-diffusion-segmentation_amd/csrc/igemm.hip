@@ -992,6 +992,7 @@ int run_cfg(int cfg, const IgemmParams& p, hipStream_t s) {
   }
   if constexpr (!LNF) {
     if (cfg == 9) return run<T, 64, BN, 4, 2, 4>(p, s);
+    if (cfg == 9) return run<T, 64, BN, 4, 2, 4>(p, s);
     if (cfg == 10) return run<T, 64, BN, 4, 2, 3>(p, s);
     switch (cfg) {
       case 2: return run<T, 256, BN, 4, 2, 3, false>(p, s);

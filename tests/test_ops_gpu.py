@@ -294,10 +294,12 @@ def attn_variant(L):
     lib.ldmseg_debug_set(2, 0)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 7])
-@pytest.mark.parametrize("B,N,Cc", [(2, 1024, 320), (1, 200, 640), (1, 4096, 320)])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 8, 9, 10])
+@pytest.mark.parametrize("B,N,Cc", [(2, 1024, 320), (1, 200, 640), (1, 4096, 320), (8, 1024, 640), (8, 1024, 320)])
 def test_attention_variants(L, attn_variant, variant, B, N, Cc):
-    """Every selectable bf16 attention kernel (attention3.hip variants 0/1/4/5/7, attention.hip 2/3) vs the fp64 reference."""
+    """Every selectable bf16 attention kernel (attention3.hip variants 0/1/4/5/6/8/9/10 - 4- and 8-wave workgroups, row
+    maxima looked at on every tile or every 4th / 16th -, attention.hip 2/3) vs the fp64 reference.  The batch-8 shapes have
+    enough workgroups for the shipped choice (0) to take its 8-wave form."""
     g = torch.Generator().manual_seed(N + Cc + variant)
     qkv = torch.randn(B, N, 3 * Cc, generator=g)
     qkv[:, :, :Cc] *= 2.0
@@ -342,6 +344,43 @@ def test_attention_running_max_paths(L, case, Cc):
     torch.cuda.synchronize()
     assert torch.isfinite(out).all()
     assert rel_err(out, ref) < 1.5e-2, case
+
+
+@pytest.mark.parametrize("variant", [0, 9, 10])
+@pytest.mark.parametrize("case", ["overflow_between_looks", "growth_between_looks"])
+@pytest.mark.parametrize("Cc", [320, 640])
+def test_attention_lazy_maxima(L, attn_variant, variant, case, Cc):
+    """The shipped kernels look at the row maxima only on tile 0 and every 16th (variant 9: 4th) key tile.  A key in a tile
+    that is NOT looked at (tile 5) whose score exceeds everything seen before by (a) far more than fp32 can hold as
+    exp2 - the row sum turns inf, the workgroup must notice and redo its rows with the maxima tracked on every tile -
+    and (b) by 2^60 - no overflow, no redo: exp2 against the stale maximum must still give the right softmax."""
+    B, N, d = 4, 2048, Cc // 8                  # 4 * 8 heads * 8 query blocks: the 8-wave form of variant 0 engages
+    g = torch.Generator().manual_seed(len(case) + Cc + variant)
+    qkv = torch.randn(B, N, 3 * Cc, generator=g)
+    q, k = qkv[:, :, :Cc], qkv[:, :, Cc:2 * Cc]
+    key = 5 * 64 + 11
+    rows = [3, 700, 1999]
+    sc = d ** -0.5 * 1.4426950408889634
+    want = 200.0 if case == "overflow_between_looks" else 60.0          # log2-domain score of the spike
+    for b, h in ((0, 0), (3, 7)):
+        for r in rows:
+            qr = torch.sign(torch.randn(d, generator=g)) * 2.0
+            q[b, r, h * d:(h + 1) * d] = qr
+        # one key aligned with the LAST of those rows (the others see a random +-; the aligned one sees |q|^2 * c)
+        c = want / (4.0 * d * sc)
+        k[b, key, h * d:(h + 1) * d] = c * q[b, rows[-1], h * d:(h + 1) * d]
+    src = bf16_round(qkv)
+    ref = attention_ref(src, B, N, Cc, model_q_rounding=True)
+    out = torch.empty(B, N, Cc, device="cuda")
+    dq = dev(qkv)
+    attn_variant(variant)
+    assert L.lib().ldmseg_op_attention(P(dq), B, N, Cc, 8, BF16, P(out), None) == 0
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    assert rel_err(out, ref) < 1.5e-2, (variant, case)
+    # the spiked row is (numerically) a copy of the spike key's value row
+    v = src[..., 2 * Cc:]
+    assert float((out[0, rows[-1], :d].cpu() - v[0, key, :d]).abs().max()) < 2e-2 * float(v.abs().max())
 
 
 def fp8_e4m3_round(t):
