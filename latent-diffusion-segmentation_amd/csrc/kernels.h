@@ -113,11 +113,14 @@ struct GNParams {
   int cpg = 0, vx = 0, ty = 0, per = 0;                 // channels per group, threads per pixel row, pixel rows per trip, pixels per chunk
   FastDiv fd_cpg, fd_vx, fd_aux;                        // aux: units / vectors per pixel of the small / fused kernels
   double inv_n = 0.0;                                   // 1 / (HW * cpg)
+  // cooperative one-pass kernel (gn_coop_kernel): hand-off records of this launch and its generation tag
+  unsigned long long* sync = nullptr;
+  unsigned gen = 0;
+  int splits = 1;                                       // workgroups that share one (image, group block)
 };
 int gn_nchunk(int B, int HW);
 int launch_groupnorm(const GNParams& p, int dtype, hipStream_t s);
-void groupnorm_set_variant(int v);   // tuning knob: bit0 = 64x64 maps on the two-launch path (no slab kernel), bit2 = 12-wave slab workgroups
-void groupnorm_set_variant(int v);   // tuning knob: bit0 = no 16-wave slab kernel (64x64 maps on the two-launch path), bit1 = slab kernel on the small maps too
+void groupnorm_set_variant(int v);   // tuning knob: bit0 = no cooperative one-pass kernel (64x64 maps on the two-launch path)
 
 // LayerNorm over the last dim of [M][C] (+ optional SiLU) - also LayerNorm2d in NHWC
 int launch_layernorm(const void* x, void* y, const float* gamma, const float* beta, int M, int C,

@@ -23,6 +23,16 @@ __device__ unsigned long long g_gn_ts[8192 * 8];
 #else
 #define GNSTAMP(slot)
 #endif
+int num_cus_gn() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
 constexpr int kMaxIter = 4;   // ceil(nvec / 256) supported (C*sizeof(T)/16 <= 1024)
 
 template <typename T>
@@ -573,6 +583,250 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const GNParams p, int GB)
   }
 }
 
+// The 64x64 maps in ONE pass with every CU streaming: S workgroups share one (image, block of GB groups whose channels make
+// whole 16-byte vectors), each keeps its HW/S pixels x GB*cpg channels in registers (10 .. 20 vectors per thread), reduces
+// them to per-group (mean, M2) - two passes over registers, torch's arithmetic -, hands the 2*GB numbers to its S-1 partners
+// and, once theirs have arrived, combines all S records in the fixed order 0..S-1 (Chan's update: exact, deterministic),
+// normalises and stores.  The tensor is read once and written once; the two-launch scheme (statistics pass + apply pass)
+// moved three times the tensor.  A register-resident slab per (image, group block) WITHOUT the split was measured first and
+// lost (tools/experiments/r03_groupnorm_register_slab_kernel.patch): 64 .. 128 workgroups cannot pull 42 MB fast enough, a
+// CU gets ~27 GB/s from beyond its L2 whatever it keeps in flight.
+// Hand-off (MI355X_MICROARCH.md, "data-tagged granules"): a record entry is ONE naturally aligned 8-byte {value, tag} written
+// by a relaxed agent-scope atomic store (global_store_dwordx2 sc1: write-through, visible across XCDs) and polled with
+// relaxed agent-scope loads until the tag equals this launch's generation - no flag, no fence, nothing to reset between
+// launches (the next launch uses the next tag; a ring of regions keeps launches on concurrent streams apart).  All
+// workgroups of the grid are co-resident by construction (the grid never exceeds one workgroup per CU), so a partner is
+// always running or about to; the poll is bounded all the same and poisons the output with NaNs on time-out instead of
+// hanging.
+template <typename T, int MAXV, int NT>
+__global__ __launch_bounds__(NT) void gn_coop_kernel(const GNParams p, int GB) {
+  constexpr int PC = Chunk<T>::N;
+  constexpr int NWV = NT / 64, MAXG = 4, MAXS = 8;
+  const int C = p.C0 + p.C1;
+  const int cpg = p.cpg;
+  const int S = p.splits;
+  const int vpp = GB * cpg / PC;                    // vectors per pixel of this group block
+  const int ppi = p.ty;                             // pixels per trip = NT / vpp (host)
+  int logical;
+  {
+    const int G = gridDim.x, bid = blockIdx.x;
+    const int q = G >> 3, r = G & 7, xcd = bid & 7, idx = bid >> 3;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;      // an image's workgroups share an XCD
+  }
+  const int slab = fd_div(logical, p.fd_vx);        // (fd_vx: divisor S)  slab = image * nblk + group block
+  const int split = logical - slab * S;
+  const int nblk = p.groups / GB;
+  const int b = fd_div(slab, p.fd_cpg);             // (fd_cpg: divisor nblk, set by the host for this kernel)
+  const int cfirst = (slab - b * nblk) * GB * cpg;
+  const int per = p.per;                            // pixels per split
+  const int pix0 = split * per, pix1 = min(p.HW, pix0 + per);
+  const int tid = threadIdx.x;
+  const int pr = fd_div(tid, p.fd_aux), j = tid - pr * vpp;
+  const bool active = pr < ppi;
+  const int c0 = cfirst + j * PC;
+  int glo = 0;
+#pragma unroll
+  for (int g = 1; g < MAXG; ++g) glo += (j * PC >= g * cpg) ? 1 : 0;
+  const int split_e = min(PC, (glo + 1) * cpg - j * PC);   // elements [0,split_e) -> group glo, the rest -> glo+1
+  const T* src;
+  int cs;
+  if (c0 < p.C0) { src = (const T*)p.src0 + (size_t)b * p.HW * p.C0 + c0; cs = p.C0; }
+  else { src = (const T*)p.src1 + (size_t)b * p.HW * p.C1 + (c0 - p.C0); cs = p.C1; }
+  u32x4 raw[MAXV];
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    const int pix = pix0 + pr + ppi * k;
+    raw[k] = (active && pix < pix1) ? *(const u32x4*)(src + (size_t)pix * cs) : u32x4{0u, 0u, 0u, 0u};
+  }
+  // ---- local statistics: one accumulator per element position (dword in bf16), combined per group afterwards: every value
+  // is consumed once, next to where it is produced.  bf16: v_dot2_f32_bf16 against (1,1) sums a dword's pair without unpacking
+  // it (group boundaries fall on dwords: cpg is even) - hipcc would otherwise keep the unpacked fp32 copies of pass 1 alive
+  // for passes 2 and 3 (8 registers per vector instead of 4; 227 VGPRs) and the grid could not be co-resident.
+  constexpr int NACC = sizeof(T) == 2 ? 4 : PC;
+  constexpr int EPA = PC / NACC;
+  float acc1[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) acc1[i] = 0.f;
+  if constexpr (sizeof(T) == 2) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    const bf2 ones = __builtin_bit_cast(bf2, 0x3f803f80u);
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned w = raw[k][i];                     // absent vectors are zero: they add nothing
+        acc1[i] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, w), ones, acc1[i], false);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+#pragma unroll
+      for (int e = 0; e < PC; ++e) acc1[e] += to_f32<T>(chunk_elem<T>(raw[k], e));
+    }
+  }
+  float slo = 0.f, shi = 0.f;
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) {
+    if (i * EPA < split_e) slo += acc1[i];
+    else shi += acc1[i];
+  }
+  __shared__ float red[2][MAXG][NWV];
+  __shared__ float s_stat[MAXG][2];
+#pragma unroll
+  for (int g = 0; g < MAXG; ++g) {
+    const float v = wave64_sum(glo == g ? slo : (glo + 1 == g ? shi : 0.f));
+    if ((tid & 63) == 0) red[0][g][tid >> 6] = v;
+  }
+  __syncthreads();
+  const float n_loc = (float)((pix1 - pix0) * cpg);          // samples per group in this split (exact: < 2^24)
+  float mlo = 0.f, mhi = 0.f, mloc[MAXG];
+#pragma unroll
+  for (int g = 0; g < MAXG; ++g) {
+    double a = 0.0;
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) a += (double)red[0][g][w];
+    mloc[g] = n_loc > 0.f ? (float)(a / (double)n_loc) : 0.f;
+    if (g == glo) mlo = mloc[g];
+    if (g == glo + 1) mhi = mloc[g];
+  }
+  {
+    float acc2[PC];
+#pragma unroll
+    for (int e = 0; e < PC; ++e) acc2[e] = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      const bool ok = active && pix0 + pr + ppi * k < pix1;
+#pragma unroll
+      for (int e = 0; e < PC; ++e) {
+        const float d = ok ? to_f32<T>(chunk_elem<T>(raw[k], e)) - (e < split_e ? mlo : mhi) : 0.f;
+        acc2[e] += d * d;
+      }
+    }
+    float qlo = 0.f, qhi = 0.f;
+#pragma unroll
+    for (int e = 0; e < PC; ++e) {
+      if (e < split_e) qlo += acc2[e];
+      else qhi += acc2[e];
+    }
+#pragma unroll
+    for (int g = 0; g < MAXG; ++g) {
+      const float v = wave64_sum(glo == g ? qlo : (glo + 1 == g ? qhi : 0.f));
+      if ((tid & 63) == 0) red[1][g][tid >> 6] = v;
+    }
+  }
+  __syncthreads();
+  // ---- publish this split's record, collect the partners', combine in split order
+  unsigned long long* rec = p.sync + (size_t)slab * (MAXS * 2 * MAXG);      // [S][2 * MAXG] granules of this slab
+  if (tid < 2 * GB) {
+    const int g = tid >> 1;
+    float v;
+    if (tid & 1) {
+      double a = 0.0;
+#pragma unroll
+      for (int w = 0; w < NWV; ++w) a += (double)red[1][g][w];
+      v = (float)a;                                                          // M2 of this split
+    } else {
+      v = mloc[g];
+    }
+    const unsigned long long gran = ((unsigned long long)p.gen << 32) | (unsigned long long)f32_bits(v);
+    __hip_atomic_store(rec + split * (2 * MAXG) + tid, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (tid < 64) {                                     // one wave polls: lane = (split, entry)
+    const int sidx = tid / (2 * MAXG), ent = tid - sidx * (2 * MAXG);
+    const bool mine = sidx < S && ent < 2 * GB;
+    unsigned long long gran = 0;
+    bool done = !mine;
+    int spins = 0;
+    while (true) {
+      if (!done) {
+        gran = __hip_atomic_load(rec + sidx * (2 * MAXG) + ent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        done = (unsigned)(gran >> 32) == p.gen;
+      }
+      if (__all(done) || ++spins > (1 << 22)) break;
+      __builtin_amdgcn_s_sleep(2);
+    }
+    const bool timeout = !__all(done);
+    const float val = timeout ? __builtin_nanf("") : bits_f32((unsigned)gran);
+    // lanes 0 .. 2*GB-1 of this wave combine entry pairs: lane g*2 takes group g (fixed split order -> deterministic)
+    float mean_s[MAXS], m2_s[MAXS];
+#pragma unroll
+    for (int sx = 0; sx < MAXS; ++sx) {
+      mean_s[sx] = __shfl(val, sx * (2 * MAXG) + (tid & (2 * MAXG - 2)), 64);
+      m2_s[sx] = __shfl(val, sx * (2 * MAXG) + (tid & (2 * MAXG - 2)) + 1, 64);
+    }
+    if (tid < 2 * GB && !(tid & 1)) {
+      double n = 0.0, mean = 0.0, m2 = 0.0;
+      for (int sx = 0; sx < S; ++sx) {
+        const int q0 = sx * per, q1 = min(p.HW, q0 + per);
+        chan_add(n, mean, m2, (double)max(0, q1 - q0) * cpg, (double)mean_s[sx], (double)m2_s[sx]);
+      }
+      const float var = n > 0.0 ? (float)(m2 / n) : 0.f;
+      s_stat[tid >> 1][0] = (float)mean;
+      s_stat[tid >> 1][1] = 1.0f / sqrtf(var + p.eps);                       // NaN on a time-out: the output says so
+    }
+  }
+  __syncthreads();
+  if (!active) return;
+  float a[PC], bb[PC];
+  {
+    const float m0 = s_stat[glo][0], r0 = s_stat[glo][1];
+    const float m1 = s_stat[glo + 1 < MAXG ? glo + 1 : glo][0], r1 = s_stat[glo + 1 < MAXG ? glo + 1 : glo][1];
+#pragma unroll
+    for (int e = 0; e < PC; ++e) {
+      a[e] = (e < split_e ? r0 : r1) * p.gamma[c0 + e];
+      bb[e] = p.beta[c0 + e] - (e < split_e ? m0 : m1) * a[e];
+    }
+  }
+  T* dst = (T*)p.out + (size_t)b * p.HW * C + c0;
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    const int pix = pix0 + pr + ppi * k;
+    if (pix < pix1) {
+      float f[PC];
+      if constexpr (sizeof(T) == 2) {
+        // (unpacked through volatile asm so that these are not the values of pass 2 kept alive - see pass 1)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const unsigned w = raw[k][i];
+          asm volatile("v_lshlrev_b32 %0, 16, %2\n\tv_and_b32 %1, 0xffff0000, %2" : "=&v"(f[2 * i]), "=&v"(f[2 * i + 1]) : "v"(w));
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < PC; ++e) f[e] = to_f32<T>(chunk_elem<T>(raw[k], e));
+      }
+#pragma unroll
+      for (int e = 0; e < PC; ++e) {
+        float y = f[e] * a[e] + bb[e];
+        if (p.silu) y = silu_f(y);
+        f[e] = y;
+      }
+      *(uint4*)(dst + (size_t)pix * C) = Chunk<T>::pack(f);
+    }
+  }
+}
+
+// per-device hand-off records of the cooperative kernel: a ring of regions (one per launch generation mod kGnRing), zeroed once
+constexpr int kGnRing = 16, kGnMaxSlabs = 2048;
+unsigned long long* gn_sync_region(unsigned* gen_out) {
+  static unsigned long long* buf[64] = {};
+  static unsigned gen[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  const size_t region = (size_t)kGnMaxSlabs * 8 * 2 * 4;                      // granules per region
+  if (!buf[dev]) {
+    void* p = nullptr;
+    if (hipMalloc(&p, region * kGnRing * sizeof(unsigned long long)) != hipSuccess) return nullptr;
+    (void)hipMemset(p, 0, region * kGnRing * sizeof(unsigned long long));
+    buf[dev] = (unsigned long long*)p;
+  }
+  if (++gen[dev] == 0) ++gen[dev];                                            // tag 0 = never written
+  *gen_out = gen[dev];
+  return buf[dev] + (size_t)(gen[dev] % kGnRing) * region;
+}
+
+int g_gn_variant = 0;   // tuning knob (ldmseg_debug_set key 8): bit0 = no cooperative kernel (64x64 maps on the two-launch path)
+
 template <typename T>
 int run_gn(const GNParams& pin, hipStream_t s) {
   constexpr int PC = Chunk<T>::N;
@@ -586,6 +840,45 @@ int run_gn(const GNParams& pin, hipStream_t s) {
   // (128 channels in bf16: cpg 4, PC 8 - the image VAE's first level)
   if (C / p.groups < PC && 2 * (C / p.groups) != PC) return -2;
   if (C / PC > 256 * kMaxIter) return -2;
+  auto try_coop = [&]() -> int {   // returns 1 when the shape is not eligible
+    // cooperative one-pass kernel: the maps the register-resident kernel above cannot hold (64x64 and up)
+    constexpr int NTC = 512, MAXVC = 21;
+    const int cpg = C / p.groups;
+    for (int GB = 1; GB <= 4; GB *= 2) {
+      if ((GB * cpg) % PC != 0 || p.groups % GB != 0 || cpg < PC || cpg % 2 != 0) continue;
+      const int vpp = GB * cpg / PC;
+      if (vpp > 64) continue;
+      const int ppi = NTC / vpp;
+      const int slabs = p.B * (p.groups / GB);
+      if (slabs > kGnMaxSlabs) continue;
+      // splits: enough workgroups for every CU, as few as the registers allow
+      int S = 1;
+      while (S < 8 && ((p.HW + S - 1) / S + ppi - 1) / ppi > MAXVC) S *= 2;
+      while (S < 8 && slabs * S * 2 <= num_cus_gn() && p.HW / (2 * S) >= ppi) S *= 2;
+      if (((p.HW + S - 1) / S + ppi - 1) / ppi > MAXVC) continue;
+      if (slabs * S > num_cus_gn()) continue;                     // every workgroup must be resident: one per CU (8 waves at ~200 registers)
+      unsigned gen = 0;
+      unsigned long long* sync = gn_sync_region(&gen);
+      if (!sync) return -3;
+      p.sync = sync; p.gen = gen; p.splits = S;
+      p.per = (p.HW + S - 1) / S;
+      p.ty = ppi;
+      p.fd_aux = fastdiv_make(vpp);
+      p.fd_vx = fastdiv_make(S);
+      p.fd_cpg = fastdiv_make(p.groups / GB);
+      hipLaunchKernelGGL((gn_coop_kernel<T, MAXVC, NTC>), dim3(slabs * S), dim3(NTC), 0, s, p, GB);
+      return hipGetLastError() == hipSuccess ? 0 : -3;
+    }
+    p.fd_cpg = fastdiv_make(p.cpg);
+    return 1;
+  };
+  // the cooperative kernel first from 32x32 maps up (measured at B = 8: 32x32 x 640 13.9 -> 11.7 us, 32x32 x 1920 29.1 -> 18.8 us,
+  // 64x64 x 320 22.9 -> 16.3 us against the paths below); tuning bit1 extends it to the 16x16 maps
+  const int coop_min_hw = (g_gn_variant & 2) ? 256 : 1024;
+  if (!(g_gn_variant & 1) && p.HW >= coop_min_hw) {
+    const int r = try_coop();
+    if (r <= 0) return r;
+  }
   {
     // single-launch register-resident kernel: GB = 1 or 2 groups per workgroup forming whole 16-byte vectors
     constexpr int MAXV = 22;
@@ -603,6 +896,10 @@ int run_gn(const GNParams& pin, hipStream_t s) {
       hipLaunchKernelGGL((gn_fused_kernel<T, MAXV>), dim3(p.groups / GB, p.B), dim3(256), 0, s, p, GB);
       return hipGetLastError() == hipSuccess ? 0 : -3;
     }
+  }
+  if (!(g_gn_variant & 1) && p.HW >= 2048) {
+    const int r = try_coop();
+    if (r <= 0) return r;
   }
   {
     constexpr int EPU = 4 / (int)sizeof(T);
@@ -697,7 +994,7 @@ int gn_nchunk(int B, int HW) {
   return n;
 }
 
-void groupnorm_set_variant(int) {}   // (tuning hook of measured-and-rejected variants: tools/experiments/r03_groupnorm_register_slab_kernel.patch)
+void groupnorm_set_variant(int v) { g_gn_variant = v; }
 
 int launch_groupnorm(const GNParams& p, int dtype, hipStream_t s) {
   return dtype == DT_BF16 ? run_gn<bf16_t>(p, s) : run_gn<float>(p, s);

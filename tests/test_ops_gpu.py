@@ -195,6 +195,46 @@ def test_groupnorm(L, dt, case):
     assert rel_err(out, ref) < (8e-3 if dt == BF16 else 5e-5), case
 
 
+@pytest.mark.parametrize("variant", [0, 1])        # cooperative one-pass kernel, and the two-launch path it replaces
+@pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("case", [
+    # B, C, C2, HW, eps, silu: the 64x64 maps of the UNet and the 128x128 ones of the 1024x1024 configuration
+    (8, 320, 0, 4096, 1e-5, 1),       # cpg 10: 4 groups per block in bf16 (5 vectors per pixel), 4 splits -> 256 workgroups
+    (4, 320, 320, 4096, 1e-5, 1),     # concat 640, cpg 20: vectors on either side of the source boundary
+    (16, 320, 0, 4096, 1e-6, 0),      # batch 16: 2 splits
+    (8, 320, 0, 3969, 1e-6, 0),       # 63 x 63: ragged splits and a ragged last trip
+    (4, 320, 0, 16384, 1e-5, 1),      # 128 x 128: 8 splits
+    (1, 640, 0, 4096, 1e-5, 1),       # one image
+])
+def test_groupnorm_cooperative(L, dt, case, variant):
+    B, Cc, C2, HW, eps, silu = case
+    g = torch.Generator().manual_seed(Cc + HW + B)
+    x = torch.randn(B, Cc, HW, generator=g) * 2 + 0.5
+    x[:, :, : HW // 3] += 3.0                      # the splits of a slab see different means: exercises the Chan combination
+    x2 = torch.randn(B, C2, HW, generator=g) - 1.0 if C2 else None
+    gamma = 1 + 0.1 * torch.randn(Cc + C2, generator=g)
+    beta = 0.1 * torch.randn(Cc + C2, generator=g)
+    xin = torch.cat([x, x2], 1) if C2 else x
+    if dt == BF16:
+        xin = bf16_round(xin)
+    ref = F.group_norm(xin, 32, gamma, beta, eps)
+    if silu:
+        ref = F.silu(ref)
+    out = torch.empty(B, Cc + C2, HW, device="cuda")
+    dx, dx2, dg, db = dev(x), dev(x2), dev(gamma), dev(beta)
+    L.lib().ldmseg_debug_set(8, variant)
+    try:
+        outs = []
+        for rep in range(3):                        # consecutive launches reuse the hand-off records under new tags
+            assert L.lib().ldmseg_op_groupnorm(P(dx), P(dx2), P(dg), P(db), B, Cc, C2, HW, eps, silu, dt, P(out), None) == 0
+            torch.cuda.synchronize()
+            outs.append(out.clone())
+    finally:
+        L.lib().ldmseg_debug_set(8, 0)
+    assert rel_err(outs[0], ref) < (8e-3 if dt == BF16 else 5e-5), case
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])       # deterministic, launch after launch
+
+
 @pytest.mark.parametrize("dt", [F32, BF16])
 @pytest.mark.parametrize("M,Cc,eps,silu", [(77, 320, 1e-5, 0), (64, 640, 1e-5, 0), (33, 1280, 1e-5, 0), (50, 256, 1e-6, 1)])
 def test_layernorm(L, dt, M, Cc, eps, silu):

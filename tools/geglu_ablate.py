@@ -6,7 +6,7 @@ M, K, N = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])   # N = GEMM colu
 x = torch.randn(M, K, device="cuda"); w = torch.randn(N, K, device="cuda") * 0.05; b = torch.zeros(N, device="cuda")
 out = torch.empty(M, N // 2, device="cuda")
 P = lambda t: C.c_void_p(t.data_ptr())
-for dbg in (0, 32, 16, 4, 1, 8, 4 | 16, 1 | 16):
-    L.ldmseg_debug_set(1, (5 << 8) | dbg)
+for dbg in [int(v, 0) for v in os.environ.get("DBGS", "0,32,16,4,1,8,20,17").split(",")]:
+    L.ldmseg_debug_set(1, (int(os.environ.get("POLICY", "61")) << 8) | dbg)
     for _ in range(2): L.ldmseg_op_linear(P(x), P(w), P(b), None, None, M, M, K, N, 1, 0, 1, 1, P(out), None)
     torch.cuda.synchronize()
