@@ -25,7 +25,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 LAT = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 DTN = sys.argv[3] if len(sys.argv) > 3 else "bf16"
 DT = {"bf16": 1, "fp32": 0}[DTN]
-NCFG = 9
+NCFG = 10
 ITERS = 30
 
 
@@ -72,7 +72,7 @@ for case in SHAPES:
         for sp in (1, 2, 3, 4, 6, 8, 12, 16):
             if sp > 1 and (geglu or ln or nk // sp < 6):
                 continue
-            bm = 256 if cfg < 3 else (128 if cfg in (3, 4, 5, 8) else 64)
+            bm = 256 if cfg < 3 else (128 if cfg in (3, 4, 5, 8) else 64)   # (6, 7, 9: 64 rows)
             items = ((M + bm - 1) // bm) * (Co // (128 if geglu else 160 if Co % 160 == 0 else 128)) * sp
             if sp > 1 and items > 1400:
                 continue
