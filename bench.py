@@ -207,6 +207,9 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="images per GPU")
     ap.add_argument("--latent", type=int, default=64)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--attention-fp8", type=int, default=0, metavar="MIN_TOKENS",
+                    help="bf16 mode: run the attention levels with at least this many tokens on the fp8 (e4m3) operand path "
+                         "(BASELINE configs[4]: --batch 4 --latent 128 --attention-fp8 16384)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-images", action="store_true", help="skip the 50-step images/s run")
     ap.add_argument("--profile-steps", type=int, default=3)
@@ -256,6 +259,8 @@ def main():
     usd = weights.generate(weights.unet_schema(12, False), seed=0)
     vsd = weights.generate(weights.vae_schema(), seed=7, norm_keys=weights.VAE_NORM_KEYS)
     unet = UNet(usd, in_channels=12, device=dev, compute_dtype=args.dtype)
+    if args.attention_fp8 > 0:
+        unet.set_attention_fp8(args.attention_fp8)
     vae = GeneralVAESeg(vsd, scaling_factor=0.18215, device=dev, compute_dtype=args.dtype)
     tr = TrainerDiffusion(vae, unet, DDIMNoiseScheduler(**SCHED_KW))
 
@@ -472,7 +477,8 @@ def main():
                     f"without cross-attention"
                     + (" (BASELINE configs[1])" if (B, L, args.dtype) == (8, 64, "bf16") and world == 1 else "")
                     + (" (BASELINE configs[2] when 8 GPUs)" if (B, L, args.dtype) == (8, 64, "bf16") and world > 1 else "")
-                    + (" (BASELINE configs[4] shape)" if (B, L) == (4, 128) else ""))
+                    + (" (BASELINE configs[4] shape)" if (B, L) == (4, 128) else "")
+                    + (f", fp8 (e4m3) attention operands on levels with >= {args.attention_fp8} tokens" if args.attention_fp8 > 0 else ""))
         out = {
             "metric": "denoising-steps/sec", "value": value, "unit": "image-steps/s", "n_gpus": distinct_devices,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,

@@ -2,7 +2,7 @@
 # Run on the GPU box from the repo root (gpurun): every measurement profiles/ holds for one round, from ONE box.
 #   bash tools/collect_profiles.sh r02     -> gpurun_out/prof_r02/...;  then locally: python tools/import_profiles.py r02
 set -x
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_$TAG; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 BENCH="python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-images --no-extras --profile-steps 0"
@@ -18,6 +18,11 @@ done
 cd $R
 bash tools/trace_layers.sh bf16 8; cp gpurun_out/trace_layers.txt $O/trace_layers_b8_l64_bf16.txt; cp gpurun_out/layers.csv $O/per_launch_events.csv
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
+# BASELINE configs[4] as lines of their own (20 steps): bf16 attention and the fp8 attention path on the 16384-token level
+python bench.py --batch 4 --latent 128 --steps 20 --warmup 2 --no-cpu-baseline --no-extras --no-images > $O/bench_config4_b4_l128_bf16.json 2>/dev/null
+python bench.py --batch 4 --latent 128 --steps 20 --warmup 2 --attention-fp8 16384 --no-cpu-baseline --no-extras --no-images > $O/bench_config4_b4_l128_fp8attn.json 2>/dev/null
+python tools/kbench.py gn > $O/kbench_groupnorm.txt 2>&1
+python tools/kbench.py attn > $O/kbench_attention.txt 2>&1
 for u in mfma_lds mfma_lds2 buf_lds valu_trans copy_floor; do [ -x tools/ubench/bin/$u ] && timeout 300 tools/ubench/bin/$u > $O/ubench_$u.txt 2>&1; done
 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; tail -2 $O/pytest_gpu.log
 find $O -name "*.db" -delete; find $O -name "*kernel_trace.csv" -size +8M -delete

@@ -4,7 +4,7 @@
 import glob, json, os, re, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src, dst = os.path.join(ROOT, "gpurun_out", f"prof_{tag}"), os.path.join(ROOT, "profiles")
 
 
@@ -28,6 +28,10 @@ for n in ("pmc_fetch", "pmc_write", "pmc_mfma"):
 for u in ("mfma_lds", "mfma_lds2", "buf_lds", "valu_trans", "copy_floor"):
     cp(f"ubench_{u}.txt", f"ubench_{u}.txt")
 cp("pytest_gpu.log", "pytest_gpu.log")
+cp("bench_config4_b4_l128_bf16.json", "bench_config4_b4_l128_bf16.json")
+cp("bench_config4_b4_l128_fp8attn.json", "bench_config4_b4_l128_fp8attn.json")
+cp("kbench_groupnorm.txt", "kbench_groupnorm.txt")
+cp("kbench_attention.txt", "kbench_attention.txt")
 
 
 def per_dispatch(path, counter, kernel):
