@@ -39,12 +39,13 @@ def sample(eps_fn, sched, rgb_latents, seed, self_condition=True, return_all=Fal
     return torch.cat(allv, dim=0) if return_all else latents
 
 
-def sample_inpaint(eps_fn, sched, rgb_latents, z0, known, seed, self_condition=True):
+def sample_inpaint(eps_fn, sched, rgb_latents, z0, known, seed, self_condition=True, noise=None):
     """known: bool [B,1,L,L], True = latent is given (trainers_ldm_cond.py:613-615
     convention).  After each step the known region is replaced by z0 re-noised
-    to the *next* timestep with the same fixed noise draw; the last step pastes z0."""
+    to the *next* timestep with the same fixed noise draw; the last step pastes z0.
+    ``noise`` (optional) = the rows of a larger batch's draw, for checking single images of that batch."""
     B, _, L, _ = rgb_latents.shape
-    noise = initial_noise(B, L, seed)
+    noise = initial_noise(B, L, seed) if noise is None else noise.clone()
     latents = noise * sched.init_noise_sigma
     cond = torch.zeros_like(rgb_latents)
     ts = sched.timesteps
