@@ -184,6 +184,7 @@ struct ConvW {
   float* bias = nullptr;  // [N]
   float* c1 = nullptr;    // [N] row sums of w when a LayerNorm is folded into this GEMM (IgemmParams::c1), else null
   int N = 0, n_valid = 0, cin_pad = 0, taps = 1, cout = 0;
+  void* w_cm = nullptr;   // 3x3 layers that may run on large maps: second packing in channel-major K order (IgemmParams::cm)
 };
 struct NormW { float* g = nullptr; float* b = nullptr; int C = 0; };
 
@@ -215,7 +216,7 @@ struct Builder {
   }
   // Conv2d / Linear: OIHW -> [Npad][k*k][cin_pad]; n_store >= Co forces explicit zero output channels
   int conv(const std::string& prefix, int Co, int Ci, int k, int cin_pad, ConvW* out, bool has_bias = true,
-           int n_store = 0, int epi = EPI_STORE) {
+           int n_store = 0, int epi = EPI_STORE, bool cm = false) {
     const float* w;
     TRY(wm->get(prefix + ".weight", (int64_t)Co * Ci * k * k, &w));
     const int nreal = n_store > Co ? n_store : Co;
@@ -228,6 +229,10 @@ struct Builder {
     out->cout = Co;
     TRY(arena->alloc(&out->w, (size_t)Npad * k * k * cin_pad * esize(dt)));
     TRY(launch_repack_conv(w, out->w, Co, Ci, k, k, Npad, cin_pad, dt, s));
+    if (cm && k == 3 && cin_pad % bke(dt) == 0 && dt == DT_BF16 && Npad % 160 == 0) {
+      TRY(arena->alloc(&out->w_cm, (size_t)Npad * k * k * cin_pad * esize(dt)));
+      TRY(launch_repack_conv(w, out->w_cm, Co, Ci, k, k, Npad, cin_pad, dt, s, bke(dt)));
+    }
     nparams += (int64_t)Co * Ci * k * k;
     if (has_bias) TRY(f32_copy(prefix + ".bias", Co, &out->bias, Npad));
     else {
@@ -318,6 +323,7 @@ struct Exec {
     p.taps = w.taps; p.stride = stride; p.up = up; p.pad = pad;
     p.M = B * Ho * Wo; p.N = w.N; p.n_valid = w.n_valid;
     p.W = w.w; p.bias = w.bias;
+    if (w.w_cm && pad < 0 && igemm_conv_cm(x.H * x.W, ctot, w.N, 3, stride, up, dt)) { p.W = w.w_cm; p.cm = 1; }
     p.rowbias = rowbias; p.rb_stride = rb_stride;
     if (resid) { p.resid = resid->p; p.ldr = resid->C; }
     p.out = out->p; p.ldo = w.n_valid;
@@ -419,9 +425,10 @@ namespace {
 int build_resnet(Builder& b, const std::string& p, int cin, int cout, int* temb_off, ResnetW* r) {
   r->cin = cin; r->cout = cout;
   TRY(b.norm(p + "norm1", cin, &r->norm1));
-  TRY(b.conv(p + "conv1", cout, cin, 3, cin, &r->conv1));
+  // (the 320- / 640-channel levels can run on maps of 64x64 and more: they also hold the channel-major packing, see igemm_conv_cm)
+  TRY(b.conv(p + "conv1", cout, cin, 3, cin, &r->conv1, true, 0, EPI_STORE, cout <= 640));
   TRY(b.norm(p + "norm2", cout, &r->norm2));
-  TRY(b.conv(p + "conv2", cout, cout, 3, cout, &r->conv2));
+  TRY(b.conv(p + "conv2", cout, cout, 3, cout, &r->conv2, true, 0, EPI_STORE, cout <= 640));
   r->has_shortcut = cin != cout;
   if (r->has_shortcut) TRY(b.conv(p + "conv_shortcut", cout, cin, 1, cin, &r->shortcut));
   r->temb_off = *temb_off;
@@ -1538,7 +1545,7 @@ int ldmseg_debug_set(int key, int value) {
   if (key == 1) { igemm_set_dbg(value); ++g_plan_epoch; return 0; }
   if (key == 5) { igemm_force_cfg(value); ++g_plan_epoch; return 0; }   // tools/tune_igemm.py: entry of igemm's instantiation list, -1 = off
   if (key == 8) { groupnorm_set_variant(value); return 0; }
-  if (key == 8) { groupnorm_set_variant(value); return 0; }
+  if (key == 9) { igemm_set_cm_mode(value); return 0; }   // K order of 3x3 conv launches: -1 rule, 0 tap-major, 1 channel-major
   if (key == 6 || key == 7) { ops_bench_knob(key, value); return 0; }   // ldmseg_bench_igemm: 6 = weight copies rotated, 7 = folded-LN launch   // bits 0-7 ablation flags (LDMSEG_IGEMM_ABLATE builds), bits 8-12 tile policy
   static unsigned long long ts_ptr = 0;                // keys 3/4: low/high half of a device stamp buffer (ablate builds)
   if (key == 3) { ts_ptr = (ts_ptr & 0xffffffff00000000ull) | (unsigned)value; igemm_set_tsbuf((void*)(uintptr_t)ts_ptr); return 0; }
@@ -1549,6 +1556,7 @@ int ldmseg_debug_set(int key, int value) {
 int ldmseg_debug_get(int key) {
   if (key == 1) return igemm_get_dbg();
   if (key == -1) return igemm_default_dbg();     // the shipped value of key 1
+  if (key == 9) return igemm_get_cm_mode();
   return 0;
 }
 

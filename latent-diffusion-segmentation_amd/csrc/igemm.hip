@@ -117,7 +117,9 @@ constexpr bool epi_stage_dedicated() { return epi_stage_bytes<BM, BN, WAVES_M, W
 // epilogue code is not free for the launches that do not use it: these kernels are ~55 KB of code each, short launches
 // run their epilogue cold out of HBM (1.6 GB of weights stream through L2 per forward), and the 64-row-tile 1x1 GEMMs
 // measured +10 us per launch with the LayerNorm branch merely present.
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int NST, bool PIPE, int LDR, bool LNF>
+// CM: channel-major K order of a 3x3 conv (IgemmParams::cm).  A separate instantiation as well: carried as a run-time
+// branch it cost every launch of the family 2-5 % (measured; scalar registers and code in the K loop's DMA step).
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int NST, bool PIPE, int LDR, bool LNF, bool CM = false>
 __global__ __launch_bounds__((WAVES_M * WAVES_N + LDR) * 64, (WAVES_M * WAVES_N + LDR) > 8 ? 3 : 2) void igemm_kernel(const IgemmParams p) {   // <=256 regs at 2 waves/SIMD; 12-wave workgroups (8 compute + 4 loader waves) need 3 per SIMD: <=168
   constexpr int NW = WAVES_M * WAVES_N;   // 4 waves (128-row tiles, 2 workgroups/CU) or 8 (256-row tiles)
   static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
@@ -201,7 +203,7 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LDR) * 64, (WAVES_M * WAVES_N 
   bool f_done = false;
   RowInfo ri[XG];
   const unsigned char* wtile0 = nullptr;
-  int f_tap = 0, f_cc = 0;
+  int f_tap = 0, f_cc = 0, f_pixb = 0;
   const unsigned char* rowptr[XG];
   unsigned rowinc[XG];
   bool need_setup = true;
@@ -225,10 +227,43 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LDR) * 64, (WAVES_M * WAVES_N 
       }
     }
     wtile0 = (const unsigned char*)p.W + (size_t)n0 * K * sizeof(T);
-    const int tiles_per_tap = Ctot / BKE;
-    f_tap = fd_div(f_kt, p.fd_tpt);
-    f_cc = (f_kt - f_tap * tiles_per_tap) * BKE;
+    if constexpr (CM) {                                  // K order [channel tile][tap]: fd_tpt divides by 9
+      const int ct = fd_div(f_kt, p.fd_tpt);
+      f_tap = f_kt - ct * 9;
+      f_cc = ct * BKE;
+#pragma unroll
+      for (int i = 0; i < XG; ++i) {                     // bit t: tap t of this row lies inside the image (rows past M: none)
+        unsigned mk = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int uy = ri[i].iy0 + t / 3, ux = ri[i].ix0 + t % 3;
+          mk |= ((uy >= 0) & (uy < p.Hi) & (ux >= 0) & (ux < p.Wi)) ? (1u << t) : 0u;
+        }
+        rowinc[i] = mk;
+      }
+    } else {
+      const int tiles_per_tap = Ctot / BKE;
+      f_tap = fd_div(f_kt, p.fd_tpt);
+      f_cc = (f_kt - f_tap * tiles_per_tap) * BKE;
+    }
     need_setup = true;
+  };
+  // Channel-major K order (IgemmParams::cm; 3x3, stride 1, no upsample): the nine taps of one 64-channel tile are
+  // consecutive K tiles, so a row's nine gathers hit lines that are at most two image rows apart - they come out of the
+  // L2 instead of making nine passes over the whole map.  rowptr[] then holds the (possibly out-of-image) address of the
+  // current tap, stepped by a wave-uniform stride per tile; rowinc[] holds the row's tap validity mask.
+  auto seg_setup_cm = [&]() __attribute__((always_inline)) {
+    const int ky = f_tap / 3, kx = f_tap - ky * 3;
+    const unsigned char* sbase;
+    int cs, coff;
+    if (f_cc < p.C0) { sbase = (const unsigned char*)p.src0; cs = p.C0; coff = f_cc; }
+    else { sbase = (const unsigned char*)p.src1; cs = p.C1; coff = f_cc - p.C0; }
+    f_pixb = cs * (int)sizeof(T);
+#pragma unroll
+    for (int i = 0; i < XG; ++i) {
+      const long long pix = (long long)(ri[i].pix_base + (ri[i].iy0 + ky) * p.Wi + ri[i].ix0 + kx);
+      rowptr[i] = sbase + (pix * cs + coff) * (long long)sizeof(T) + ld_j * 16;
+    }
   };
   // A "segment" is a run of K tiles inside one (tap, source tensor): there the gather address of a
   // row only advances by 128 B per tile.  Row pointers are set up once per segment; rows whose tap
@@ -258,13 +293,34 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LDR) * 64, (WAVES_M * WAVES_N 
       if (f_item >= nwork) { f_done = true; return false; }
       item_setup();
     }
-    if (need_setup) seg_setup();
     // (values below are wave-uniform; readfirstlane makes that provable so they can live in SGPRs)
     const unsigned dst = __builtin_amdgcn_readfirstlane(lds_wave + (unsigned)stage * (unsigned)kStageBytes);
+#ifdef LDMSEG_IGEMM_SKIPX     // probe: X bytes of a halo-resident conv (same DMA instruction count, 1 lane instead of 64 on 5 of 6 tiles)
+    const bool xfull = (p.taps != 9) || (f_kt % LDMSEG_IGEMM_SKIPX) == 0;
+#else
+    constexpr bool xfull = true;
+#endif
+    if constexpr (CM) {
+      if (need_setup) seg_setup_cm();
+      const int tap = __builtin_amdgcn_readfirstlane(f_tap);
+      // stride to the next stream position: next tap in the row, first tap of the next image row, or back to tap 0 of
+      // the next channel tile
+      const int kx = tap - (tap / 3) * 3;
+      const long long step = __builtin_amdgcn_readfirstlane(
+          tap == 8 ? kRowBytes - (2 * p.Wi + 2) * f_pixb : (kx == 2 ? (p.Wi - 2) * f_pixb : f_pixb));
 #pragma unroll
-    for (int i = 0; i < XG; ++i) {
-      glds16(rowptr[i], dst + i * (NLW * 1024));
-      rowptr[i] += rowinc[i];
+      for (int i = 0; i < XG; ++i) {
+        const unsigned char* src = ((rowinc[i] >> tap) & 1u) ? rowptr[i] : zpage;
+        if (xfull || lane == 0) glds16(src, dst + i * (NLW * 1024));
+        rowptr[i] += step;
+      }
+    } else {
+      if (need_setup) seg_setup();
+#pragma unroll
+      for (int i = 0; i < XG; ++i) {
+        if (xfull || lane == 0) glds16(rowptr[i], dst + i * (NLW * 1024));
+        rowptr[i] += rowinc[i];
+      }
     }
     const unsigned long long wt_u = (unsigned long long)(uintptr_t)(wtile0 + (size_t)f_kt * kRowBytes);
     const unsigned wt_lo = __builtin_amdgcn_readfirstlane((unsigned)wt_u);
@@ -275,9 +331,14 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LDR) * 64, (WAVES_M * WAVES_N 
     for (int i = 0; i < WG; ++i)
       if ((i + 1 < WG || w_last) && !DBG(p, 2)) glds16_sbase(woff[i], wt, wdst + i * (NLW * 1024));
     ++f_kt;
-    f_cc += BKE;
-    if (f_cc == Ctot) { f_cc = 0; ++f_tap; }
-    need_setup = (f_cc == 0) | (f_cc == p.C0);
+    if constexpr (CM) {
+      need_setup = false;
+      if (++f_tap == 9) { f_tap = 0; f_cc += BKE; need_setup = (f_cc == p.C0); }
+    } else {
+      f_cc += BKE;
+      if (f_cc == Ctot) { f_cc = 0; ++f_tap; }
+      need_setup = (f_cc == 0) | (f_cc == p.C0);
+    }
     return true;
   };
   // wait until at most AHEAD of this wave's per-tile DMA batches are still in flight
@@ -902,6 +963,7 @@ int g_big = kDefaultPolicy;      // bit0: 8-wave 256-row tiles with a 3-stage ri
                      // tiles (+ loader waves on long K); bit5: loader waves on the 256-row tiles (long K / GEGLU)
 
 int g_force_cfg = -1;            // tools/tune_igemm.py: run every launch with this entry of the instantiation list
+int g_cm_mode = -1;              // igemm_set_cm_mode
 
 // Launch table measured on the MI355X (tools/tune_igemm.py): launch shape -> entry of the instantiation list in run_cfg()
 // + number of K slices.  Shapes that are not listed (other batch sizes, other models) use the rules in dispatch() /
@@ -921,7 +983,7 @@ const TunedEntry* tuned_lookup(const IgemmParams& p, int dtype) {
   return nullptr;
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int NST = 2, bool PIPE = false, int LDR = 0, bool LNF = false>
+template <typename T, int BM, int BN, int WM, int WN, int NST = 2, bool PIPE = false, int LDR = 0, bool LNF = false, bool CM = false>
 int run(const IgemmParams& pin, hipStream_t s) {
   IgemmParams p = pin;
   p.dbg = g_dbg;
@@ -934,7 +996,7 @@ int run(const IgemmParams& pin, hipStream_t s) {
   p.fd_nt = fastdiv_make(nt);
   p.fd_ntiles = fastdiv_make(mt * nt);
   p.fd_nsplit = fastdiv_make(p.splits > 1 ? p.splits : 1);
-  p.fd_tpt = fastdiv_make((p.C0 + p.C1) / (int)(kRowBytes / sizeof(T)));
+  p.fd_tpt = fastdiv_make(CM ? 9 : (p.C0 + p.C1) / (int)(kRowBytes / sizeof(T)));   // CM: K tiles per channel tile
   const int nwork = mt * nt * (p.splits > 1 ? p.splits : 1);
   // persistent grid: as many workgroups as fit on the chip at once (2 per CU for the 4-wave tiles,
   // 1 per CU for the 8-wave ones); each walks nwork / grid items
@@ -942,7 +1004,7 @@ int run(const IgemmParams& pin, hipStream_t s) {
   const int grid_x = nwork < resident ? nwork : resident;
   const size_t lds = (size_t)NST * (BM + BN) * kRowBytes +
                      (epi_stage_dedicated<BM, BN, WM, WN>() ? epi_stage_bytes<BM, BN, WM, WN>() : 0);
-  auto kern = igemm_kernel<T, BM, BN, WM, WN, NST, PIPE, LDR, LNF>;
+  auto kern = igemm_kernel<T, BM, BN, WM, WN, NST, PIPE, LDR, LNF, CM>;
   static bool attr_set[kMaxDev] = {};
   const int dev = cur_dev();
   if (!attr_set[dev]) {
@@ -950,7 +1012,7 @@ int run(const IgemmParams& pin, hipStream_t s) {
     attr_set[dev] = true;
   }
   g_last = IgemmDispatch{(int)sizeof(T) == 2 ? DT_BF16 : DT_F32, BM, BN, WM, WN, NST, PIPE ? 1 : 0, LDR,
-                         p.splits > 1 ? p.splits : 1, grid_x, LNF ? 1 : 0};
+                         p.splits > 1 ? p.splits : 1, grid_x, LNF ? 1 : 0, CM ? 1 : 0};
   if (g_log_on) g_log.insert(igemm_dispatch_name(g_last));
   hipLaunchKernelGGL(kern, dim3(grid_x), dim3((WM * WN + LDR) * 64), lds, s, p);
   if (p.splits > 1) {
@@ -977,8 +1039,7 @@ inline bool mid8_ok(long t128, int splits) {
 //   2  256 rows, 8 waves, plain K loop           5  128 rows, 4 waves, 4-stage ring (one workgroup per CU)
 //   6  64 rows, 4 waves, 4-stage ring            7  64 rows, 4 waves, two workgroups per CU
 //   8  128 rows, 4 waves, two workgroups per CU  9  64 rows, 8 waves (16 x 80 wave tiles), 4-stage ring
-//   10 64 rows, 8 waves, 3-stage ring
-constexpr int kNumCfg = 11;
+constexpr int kNumCfg = 10;
 template <typename T, int BN, bool LNF>
 int run_cfg(int cfg, const IgemmParams& p, hipStream_t s) {
   switch (cfg) {
@@ -992,8 +1053,6 @@ int run_cfg(int cfg, const IgemmParams& p, hipStream_t s) {
   }
   if constexpr (!LNF) {
     if (cfg == 9) return run<T, 64, BN, 4, 2, 4>(p, s);
-    if (cfg == 9) return run<T, 64, BN, 4, 2, 4>(p, s);
-    if (cfg == 10) return run<T, 64, BN, 4, 2, 3>(p, s);
     switch (cfg) {
       case 2: return run<T, 256, BN, 4, 2, 3, false>(p, s);
       case 3: return run<T, 128, BN, 2, 2, 4, true, 4>(p, s);
@@ -1032,6 +1091,12 @@ int dispatch_ln(const IgemmParams& p, hipStream_t s) {
 
 template <typename T>
 int dispatch(const IgemmParams& p, hipStream_t s) {
+  if (p.cm) {   // channel-major 3x3 conv: one instantiation (the 256-row loader-wave tile the large maps use anyway), bf16 only
+    if constexpr (sizeof(T) == 2) {
+      if (!p.rowstats && p.epi == EPI_STORE && p.N % 160 == 0) return run<T, 256, 160, 4, 2, 3, true, 4, false, true>(p, s);
+    }
+    return -2;
+  }
   {
     int cfg = g_force_cfg;
     if (cfg < 0) {
@@ -1102,8 +1167,8 @@ IgemmDispatch igemm_last_dispatch() { return g_last; }
 // "igemm<dtype,BM,BN,WM,WN,NST,PIPE,LDR>" + "/splitk" when the launch ran K slices (partial epilogue + finish kernel)
 std::string igemm_dispatch_name(const IgemmDispatch& d) {
   char buf[96];
-  std::snprintf(buf, sizeof buf, "igemm<%s,%d,%d,%d,%d,%d,%d,%d%s>%s", d.dtype == DT_BF16 ? "bf16" : "f32", d.bm, d.bn, d.wm, d.wn,
-                d.nst, d.pipe, d.ldr, d.lnf ? ",ln" : "", d.splits > 1 ? "/splitk" : "");
+  std::snprintf(buf, sizeof buf, "igemm<%s,%d,%d,%d,%d,%d,%d,%d%s%s>%s", d.dtype == DT_BF16 ? "bf16" : "f32", d.bm, d.bn, d.wm, d.wn,
+                d.nst, d.pipe, d.ldr, d.lnf ? ",ln" : "", d.cm ? ",cm" : "", d.splits > 1 ? "/splitk" : "");
   return buf;
 }
 void igemm_log_enable(int on) { g_log_on = on != 0; if (on) g_log.clear(); }
@@ -1153,11 +1218,19 @@ size_t igemm_partial_bytes(const IgemmParams& p) {
   return p.splits > 1 ? (size_t)p.splits * p.M * p.N * sizeof(float) : 0;
 }
 
+void igemm_set_cm_mode(int mode) { g_cm_mode = mode < -1 || mode > 1 ? -1 : mode; }
+int igemm_get_cm_mode() { return g_cm_mode; }
+bool igemm_conv_cm(int hw, int ctot, int n, int k, int stride, int up, int dtype) {
+  if (k != 3 || stride != 1 || up || g_cm_mode == 0 || dtype != DT_BF16 || n % 160 != 0) return false;   // (what dispatch() can run)
+  return g_cm_mode == 1 || (hw >= 4096 && ctot >= 640);
+}
+
 int launch_igemm(const IgemmParams& p, int dtype, hipStream_t s) {
   const int bke = dtype == DT_BF16 ? 64 : 32;
   if (p.M <= 0 || p.N <= 0 || p.N % 32 != 0) return -2;
   if (p.C0 % bke != 0 || p.C1 % bke != 0 || (p.C0 + p.C1) == 0) return -2;
   if (p.taps != 1 && p.taps != 9) return -2;
+  if (p.cm && (p.taps != 9 || p.stride != 1 || p.up || (p.pad >= 0 && p.pad != 1))) return -2;
   if (p.n_valid % 4 != 0 && p.epi != EPI_NCHW_F32) return -2;
   if (p.epi == EPI_GEGLU && p.N % 128 != 0) return -2;
   if (p.splits > 1 && (p.epi != EPI_STORE || p.partial == nullptr)) return -2;

@@ -50,6 +50,8 @@ struct IgemmParams {
                     // (diffusers Downsample2D(padding=0) of the AutoencoderKL encoder); the bottom/right edge is bounds-checked
   int stride = 1;   // 1 | 2
   int up = 0;       // nearest x2 upsample folded into the gather (Upsample2D)
+  int cm = 0;       // 3x3 only: W is packed in channel-major K order, k = (channel tile, tap, channel in tile), instead of
+                    // (tap, channel); needs stride 1, pad 1, no upsample (launch_igemm checks)
   int M = 0;        // B*Ho*Wo
   int N = 0;        // packed rows of W (multiple of the N tile)
   int n_valid = 0;  // real output channels (store mask)
@@ -89,11 +91,18 @@ void attention_set_qf1(int v);    // tuning knob: force 16 query rows per wave
 void igemm_set_tsbuf(void* dev_buf);   // LDMSEG_IGEMM_ABLATE builds only
 void igemm_set_dbg(int flags);
 void ops_bench_knob(int key, int value);   // ldmseg_bench_igemm (ops_api.hip): 6 = number of weight copies rotated, 7 = folded-LN launch
+// K order a 3x3 conv launch uses: -1 = the shipped rule (channel-major for stride-1 convs without upsample on maps of
+// >= 4096 pixels with >= 640 input channels: there one tap sweep over the X operand no longer fits an XCD's L2 and the
+// channel-major order measured -6 %; smaller launches measured +2..8 % and keep the tap-major order), 0 = tap-major
+// everywhere, 1 = channel-major wherever the kernel supports it.  Layers that can meet the rule hold both packings.
+void igemm_set_cm_mode(int mode);
+int igemm_get_cm_mode();
+bool igemm_conv_cm(int hw, int ctot, int n, int k, int stride, int up, int dtype);
 void igemm_force_cfg(int cfg);   // tuning tool: >= 0 runs every launch with that entry of the instantiation list, -1 = off
 int igemm_get_dbg();       // current (policy << 8) | ablation flags
 int igemm_default_dbg();   // the shipped value
 // template instantiation + plan of the most recent launch_igemm (test introspection)
-struct IgemmDispatch { int dtype, bm, bn, wm, wn, nst, pipe, ldr, splits, grid, lnf; };
+struct IgemmDispatch { int dtype, bm, bn, wm, wn, nst, pipe, ldr, splits, grid, lnf, cm; };
 IgemmDispatch igemm_last_dispatch();
 std::string igemm_dispatch_name(const IgemmDispatch& d);
 void igemm_log_enable(int on);      // start (and clear) / stop recording the distinct instantiations launched
@@ -164,8 +173,9 @@ int launch_bilinear2x_argmax(const void* x, int64_t* ids, float* prob, int B, in
 
 // weight repack (f32 torch layout -> compute dtype [N][K])
 // conv OIHW [Co][Ci][kh][kw] -> [Npad][kh*kw][Cipad] ; rows >= Co and channels >= Ci are zero
+// cm_tile > 0: channel-major K order [Npad][Cipad / cm_tile][kh*kw][cm_tile] (IgemmParams::cm; cm_tile = K elements per tile)
 int launch_repack_conv(const float* w, void* out, int Co, int Ci, int KH, int KW, int Npad, int Cipad,
-                       int dtype, hipStream_t s);
+                       int dtype, hipStream_t s, int cm_tile = 0);
 // generic row gather: out[r][:] = (src_row[r] >= 0) ? w[src_row[r]][0:K] : 0  (Linear, GEGLU interleave, qkv concat)
 int launch_repack_rows(const float* w, void* out, const int* src_row_dev, int Npad, int K, int dtype, hipStream_t s);
 // ConvTranspose2d [Ci][Co][2][2] -> [4*Co][Ci]  (n = (dy*2+dx)*Co + co)

@@ -182,13 +182,24 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* s, T* p,
 
 // ---------------------------------------------------------------- weight repack
 template <typename T>
-__global__ void repack_conv_kernel(const float* w, T* out, int Co, int Ci, int KH, int KW, int Npad, int Cipad) {
+__global__ void repack_conv_kernel(const float* w, T* out, int Co, int Ci, int KH, int KW, int Npad, int Cipad, int cm_tile) {
   const size_t total = (size_t)Npad * KH * KW * Cipad;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int c = (int)(i % Cipad);
-    const size_t r = i / Cipad;
-    const int tap = (int)(r % (KH * KW));
-    const int n = (int)(r / (KH * KW));
+    int c, tap, n;
+    if (cm_tile > 0) {                    // [n][channel tile][tap][channel in tile]
+      const int ci = (int)(i % cm_tile);
+      size_t r = i / cm_tile;
+      tap = (int)(r % (KH * KW));
+      r /= (KH * KW);
+      const int tiles = Cipad / cm_tile;
+      c = (int)(r % tiles) * cm_tile + ci;
+      n = (int)(r / tiles);
+    } else {                              // [n][tap][channel]
+      c = (int)(i % Cipad);
+      const size_t r = i / Cipad;
+      tap = (int)(r % (KH * KW));
+      n = (int)(r / (KH * KW));
+    }
     float v = 0.f;
     if (n < Co && c < Ci) v = w[(((size_t)n * Ci + c) * KH * KW) + tap];
     out[i] = from_f32<T>(v);
@@ -349,12 +360,13 @@ int launch_softmax_rows(const float* sc, void* p, int rows, int n, float scale, 
 }
 
 int launch_repack_conv(const float* w, void* out, int Co, int Ci, int KH, int KW, int Npad, int Cipad, int dtype,
-                       hipStream_t s) {
+                       hipStream_t s, int cm_tile) {
   const size_t total = (size_t)Npad * KH * KW * Cipad;
+  if (cm_tile > 0 && Cipad % cm_tile != 0) return -2;
   if (dtype == DT_BF16)
-    hipLaunchKernelGGL(repack_conv_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, w, (bf16_t*)out, Co, Ci, KH, KW, Npad, Cipad);
+    hipLaunchKernelGGL(repack_conv_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, s, w, (bf16_t*)out, Co, Ci, KH, KW, Npad, Cipad, cm_tile);
   else
-    hipLaunchKernelGGL(repack_conv_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, w, (float*)out, Co, Ci, KH, KW, Npad, Cipad);
+    hipLaunchKernelGGL(repack_conv_kernel<float>, dim3(grid_for(total)), dim3(256), 0, s, w, (float*)out, Co, Ci, KH, KW, Npad, Cipad, cm_tile);
   return ok();
 }
 

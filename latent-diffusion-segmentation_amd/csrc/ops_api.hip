@@ -322,6 +322,7 @@ static int op_igemm_impl(const float* x, const float* x2, const float* w, const 
   const int Np = rupi(Co, bn);
   const int ct = c0 + c1;
   const int cout = geglu ? Co / 2 : Co;
+  const bool cm = !geglu && igemm_conv_cm(H * W, c0 + c1, Np, k, stride, up, dtype) && (Ci % a) == 0 && (!Ci2 || (Ci2 % a) == 0);   // the engine's rule
   void* wp = t.get((size_t)Np * k * k * ct * es(dtype));
   float* bp = (float*)t.get(Np * sizeof(float));
   (void)hipMemsetAsync(bp, 0, Np * sizeof(float), s);
@@ -336,14 +337,14 @@ static int op_igemm_impl(const float* x, const float* x2, const float* w, const 
     if (launch_repack_rows(w, wp, dmap, Np, ct, dtype, s)) return -3;
     if (bias && launch_repack_rows(bias, bp, dmap, Np, 1, DT_F32, s)) return -3;
   } else if (!Ci2) {
-    if (launch_repack_conv(w, wp, Co, Ci, k, k, Np, c0, dtype, s)) return -3;
+    if (launch_repack_conv(w, wp, Co, Ci, k, k, Np, c0, dtype, s, cm ? a : 0)) return -3;
     if (bias) (void)hipMemcpyAsync(bp, bias, Co * sizeof(float), hipMemcpyDeviceToDevice, s);
   } else {
     void* w_cat = t.get((size_t)Co * ct * k * k * sizeof(float));
     (void)hipMemsetAsync(w_cat, 0, (size_t)Co * ct * k * k * sizeof(float), s);
     (void)hipMemcpy2DAsync(w_cat, (size_t)ct * k * k * sizeof(float), w, (size_t)(Ci + Ci2) * k * k * sizeof(float),
                            (size_t)(Ci + Ci2) * k * k * sizeof(float), Co, hipMemcpyDeviceToDevice, s);
-    if (launch_repack_conv((const float*)w_cat, wp, Co, ct, k, k, Np, ct, dtype, s)) return -3;
+    if (launch_repack_conv((const float*)w_cat, wp, Co, ct, k, k, Np, ct, dtype, s, cm ? a : 0)) return -3;
     if (bias) (void)hipMemcpyAsync(bp, bias, Co * sizeof(float), hipMemcpyDeviceToDevice, s);
   }
   const int Hl = up ? 2 * H : H, Wl = up ? 2 * W : W;
@@ -356,7 +357,7 @@ static int op_igemm_impl(const float* x, const float* x2, const float* w, const 
   void* op = t.get((size_t)B * Ho * Wo * cout * es(dtype));
   IgemmParams p;
   p.src0 = xp; p.C0 = c0; p.src1 = x2p; p.C1 = c1;
-  p.B = B; p.Hi = H; p.Wi = W; p.Ho = Ho; p.Wo = Wo; p.taps = k * k; p.stride = stride; p.up = up;
+  p.B = B; p.Hi = H; p.Wi = W; p.Ho = Ho; p.Wo = Wo; p.taps = k * k; p.stride = stride; p.up = up; p.cm = cm ? 1 : 0;
   p.M = B * Ho * Wo; p.N = Np; p.n_valid = cout; p.W = wp; p.bias = bp;
   p.rowbias = rowbias; p.rb_stride = Co;
   p.resid = rp; p.ldr = cout; p.out = op; p.ldo = cout; p.epi = epi; p.silu = silu;

@@ -573,6 +573,71 @@ def test_igemm_tile_policies_agree(L, tile_policy, policy, shape):
     assert rel_err(out, ref) < 8e-3, (policy, shape, L.igemm_last_kernel())
 
 
+@pytest.fixture
+def k_order(L):
+    """K order in which op_igemm packs 3x3 weights (debug key 9); the previous value is restored afterwards."""
+    lib = L.lib()
+    saved = lib.ldmseg_debug_get(9)
+
+    def set_mode(mode):
+        assert lib.ldmseg_debug_set(9, mode) == 0
+    yield set_mode
+    lib.ldmseg_debug_set(9, saved)
+    assert lib.ldmseg_debug_get(9) == saved == -1
+
+
+# (B, Ci, Ci2, H, Co, splits, residual, time-embedding row)
+K_ORDER_CASES = {
+    "big": (8, 320, 0, 64, 320, 0, 0, 1),            # 256x160 loader-wave tiles, 45 K tiles
+    "concat": (2, 640, 320, 64, 320, 0, 1, 0),       # torch.cat partner: the source switches at a channel-tile boundary
+    "mid": (8, 320, 0, 32, 640, 0, 0, 1),            # 128-row loader-wave tiles
+    "ragged": (3, 128, 64, 20, 160, 0, 1, 0),        # M = 1200: last tile partly past M, images end inside tiles
+    "tiny_maps": (8, 256, 0, 8, 1280, 0, 0, 0),      # 8x8 maps: a 64-row tile spans several images, every row has padding taps
+    "splitk": (2, 1280, 0, 16, 1280, 4, 0, 1),       # K slices start in the middle of a channel tile (180 K tiles / 4)
+    "splitk3": (1, 640, 0, 16, 320, 7, 0, 0),        # 90 K tiles over 7 slices: every slice starts at a different tap
+}
+
+
+@pytest.mark.parametrize("policy", [None, 0])
+@pytest.mark.parametrize("case", sorted(K_ORDER_CASES))
+def test_conv3x3_k_orders_agree(L, tile_policy, k_order, case, policy):
+    """3x3 conv weights are packed (tap, channel) or (channel tile, tap, channel) - the order large maps with many input
+    channels use so that a row's nine gathers stay inside the L2 (bf16 only; one dedicated instantiation, whatever the tile
+    policy).  Both orders against F.conv2d; the two HIP results differ only by fp32 summation order."""
+    dt = BF16
+    B, Ci, Ci2, H, Co, splits, use_res, use_rb = K_ORDER_CASES[case]
+    g = torch.Generator().manual_seed(len(case) * 13 + Ci)
+    ct = Ci + Ci2
+    x = torch.randn(B, Ci, H, H, generator=g)
+    x2 = torch.randn(B, Ci2, H, H, generator=g) if Ci2 else None
+    w = torch.randn(Co, ct, 3, 3, generator=g) / (ct * 9) ** 0.5
+    b = torch.randn(Co, generator=g)
+    rb = torch.randn(B, Co, generator=g) if use_rb else None
+    xin = torch.cat([x, x2], 1) if Ci2 else x
+    rnd = bf16_round if dt == BF16 else (lambda t: t)
+    ref = F.conv2d(rnd(xin), rnd(w), b, padding=1)
+    if rb is not None:
+        ref = ref + rb[:, :, None, None]
+    res = torch.randn(ref.shape, generator=g) if use_res else None
+    if res is not None:
+        ref = ref + rnd(res)
+    dx, dx2, dw, db, dres, drb = dev(x), dev(x2), dev(w), dev(b), dev(res), dev(rb)
+    if policy is not None:
+        tile_policy(policy)
+    outs = []
+    for mode in (0, 1):
+        k_order(mode)
+        out = torch.empty(ref.shape, device="cuda")
+        assert L.lib().ldmseg_op_igemm(P(dx), P(dx2), P(dw), P(db), P(dres), P(drb), B, Ci, Ci2, H, H, Co, 3, 1, 0, 0, 0,
+                                       splits, dt, P(out), None) == 0, L.lib().ldmseg_last_error()
+        torch.cuda.synchronize()
+        outs.append(out.cpu())
+        tol = 8e-3 if dt == BF16 else 2e-4
+        assert rel_err(outs[-1], ref) < tol, (case, mode, policy, L.igemm_last_kernel())
+        assert (",cm" in L.igemm_last_kernel()) == (mode == 1), L.igemm_last_kernel()
+    assert rel_err(outs[1], outs[0]) < 8e-3
+
+
 def test_shipped_policy_is_active_after_the_policy_tests(L):
     assert L.lib().ldmseg_debug_get(1) == L.lib().ldmseg_debug_get(-1)
 

@@ -294,6 +294,32 @@ def test_bf16_trajectory_parity(unets, unet_sd, vae_sd, sched_kw):
     assert agree_bf16 > 0.93 and agree_modes > 0.93
 
 
+def test_unet_conv_k_order_modes_agree(unets):
+    """The 3x3 convs of the 320- / 640-channel levels hold two weight packings ((tap, channel) and (channel tile, tap,
+    channel)); a bf16 launch picks by map size.  Forcing either order everywhere must give the same forward up to rounding
+    flips of intermediate activations."""
+    from ldmseg_amd import _lib
+    lib = _lib.lib()
+    assert lib.ldmseg_debug_get(9) == -1
+    x = torch.randn(2, 12, 64, 64, generator=torch.Generator().manual_seed(11)).to(DEV)
+    outs = {}
+    try:
+        for mode in (-1, 0, 1):
+            assert lib.ldmseg_debug_set(9, mode) == 0
+            for dt in ("fp32", "bf16"):
+                outs[mode, dt] = unets[dt](x, 500).sample.clone()
+    finally:
+        lib.ldmseg_debug_set(9, -1)
+    l2 = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    for mode in (0, 1):
+        e16 = l2(outs[mode, "bf16"], outs[-1, "bf16"])
+        print(f"K order {mode} vs rule: bf16 {e16:.2e}")
+        assert e16 < 3e-2          # (bf16 against the fp32 oracle is 1.5e-2: rounding flips, not the order, set this scale)
+        assert torch.equal(outs[mode, "fp32"], outs[-1, "fp32"])  # the fp32 parity mode has the tap-major order only
+    assert not torch.equal(outs[0, "bf16"], outs[1, "bf16"])      # the two orders really are different code paths
+    assert not torch.equal(outs[0, "bf16"], outs[-1, "bf16"])     # and the shipped rule uses the channel-major one at 64x64
+
+
 def test_unet_forward_parts_equals_concat(unets):
     u = unets["fp32"]
     g = torch.Generator().manual_seed(3)
