@@ -583,6 +583,135 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const GNParams p, int GB)
   }
 }
 
+// gn_fused_kernel with the dependent chain cut down - at these sizes (1 .. 10 MB) the kernel is a latency chain, not a
+// stream: [loads] -> reduce -> barrier -> reduce -> barrier -> [gamma / beta loads] -> store became
+// [loads of data, gamma, beta and the groups' shift samples, all issued together] -> ONE reduction -> barrier -> store.
+// The statistics are shifted sums around a sample of the group itself (its first element): sum(x - K) and sum((x - K)^2)
+// in one pass over the registers; with K a member of the group |mean - K| is a few standard deviations at most, so
+// var = E[(x-K)^2] - E[x-K]^2 loses nothing to cancellation (a mean of 1000 with deviation 1 is a test case).  MAXV is a
+// template parameter chosen by the launcher (2 / 6 / 12 / 22): the register loops carry no dead iterations.
+template <typename T, int MAXV>
+__global__ __launch_bounds__(256) void gn_one_kernel(const GNParams p, int GB) {
+  constexpr int PC = Chunk<T>::N;
+  const int C = p.C0 + p.C1;
+  const int cpg = p.cpg;
+  const int vpp = GB * cpg / PC;
+  const int ppi = p.ty;
+  const int b = blockIdx.y;
+  const int cfirst = blockIdx.x * GB * cpg;
+  const int tid = threadIdx.x;
+  const int pr = fd_div(tid, p.fd_aux), j = tid - pr * vpp;
+  const bool active = pr < ppi;
+  const int c0 = cfirst + j * PC;
+  const int glo = (j * PC) >= cpg ? 1 : 0;
+  const int split = min(PC, (glo + 1) * cpg - j * PC);
+  const T* src;
+  int cs;
+  if (c0 < p.C0) { src = (const T*)p.src0 + (size_t)b * p.HW * p.C0 + c0; cs = p.C0; }
+  else { src = (const T*)p.src1 + (size_t)b * p.HW * p.C1 + (c0 - p.C0); cs = p.C1; }
+  u32x4 raw[MAXV];
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    const int pix = pr + ppi * k;
+    raw[k] = (active && pix < p.HW) ? *(const u32x4*)(src + (size_t)pix * cs) : u32x4{0u, 0u, 0u, 0u};
+  }
+  // shift samples: pixel 0 of the first channel of the block's group(s) - the same two addresses for every thread
+  float K[2];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const int c = cfirst + (g < GB ? g : 0) * cpg;
+    const T* sp = c < p.C0 ? (const T*)p.src0 + (size_t)b * p.HW * p.C0 + c : (const T*)p.src1 + (size_t)b * p.HW * p.C1 + (c - p.C0);
+    K[g] = to_f32<T>(*sp);
+  }
+  // affine parameters of this thread's channels: requested now, used after the barrier
+  float ga[PC], be[PC];
+  if (active) {
+#pragma unroll
+    for (int e = 0; e < PC; e += 4) {
+      const f32x4 g4 = *(const f32x4*)(p.gamma + c0 + e), b4 = *(const f32x4*)(p.beta + c0 + e);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { ga[e + r] = g4[r]; be[e + r] = b4[r]; }
+    }
+  }
+  const float klo = glo == 0 ? K[0] : K[1], khi = K[1];
+  float slo = 0.f, shi = 0.f, qlo = 0.f, qhi = 0.f;
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    if (active && pr + ppi * k < p.HW) {
+#pragma unroll
+      for (int e = 0; e < PC; ++e) {
+        const float f = to_f32<T>(chunk_elem<T>(raw[k], e));
+        if (e < split) { const float d = f - klo; slo += d; qlo += d * d; }
+        else { const float d = f - khi; shi += d; qhi += d * d; }
+      }
+    }
+  }
+  __shared__ float red[4][4];     // [sum g0, sum g1, sq g0, sq g1][wave]
+  {
+    const float s0 = wave64_sum(glo == 0 ? slo : 0.f), s1 = wave64_sum(glo == 0 ? shi : slo);
+    const float q0 = wave64_sum(glo == 0 ? qlo : 0.f), q1 = wave64_sum(glo == 0 ? qhi : qlo);
+    if ((tid & 63) == 0) { red[0][tid >> 6] = s0; red[1][tid >> 6] = s1; red[2][tid >> 6] = q0; red[3][tid >> 6] = q1; }
+  }
+  __syncthreads();
+  float mean[2], var[2], rstd[2];
+  const float inv_n = (float)p.inv_n;
+  bool far = false;
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const float ms = (((red[g][0] + red[g][1]) + red[g][2]) + red[g][3]) * inv_n;           // E[x - K]
+    const float m2 = (((red[2 + g][0] + red[2 + g][1]) + red[2 + g][2]) + red[2 + g][3]) * inv_n;   // E[(x - K)^2]
+    mean[g] = K[g] + ms;
+    var[g] = fmaxf(m2 - ms * ms, 0.f);
+    far |= ms * ms > 64.f * var[g];      // the sample was an outlier of its group (same verdict in every thread)
+  }
+  if (far) {                             // rare: second moment again, centred on the mean that is known now
+    const float mlo = glo == 0 ? mean[0] : mean[1], mhi = mean[1];
+    qlo = 0.f; qhi = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      if (active && pr + ppi * k < p.HW) {
+#pragma unroll
+        for (int e = 0; e < PC; ++e) {
+          const float f = to_f32<T>(chunk_elem<T>(raw[k], e));
+          if (e < split) { const float d = f - mlo; qlo += d * d; }
+          else { const float d = f - mhi; qhi += d * d; }
+        }
+      }
+    }
+    const float q0 = wave64_sum(glo == 0 ? qlo : 0.f), q1 = wave64_sum(glo == 0 ? qhi : qlo);
+    __syncthreads();                     // everybody has read the first round's records
+    if ((tid & 63) == 0) { red[2][tid >> 6] = q0; red[3][tid >> 6] = q1; }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < 2; ++g) var[g] = (((red[2 + g][0] + red[2 + g][1]) + red[2 + g][2]) + red[2 + g][3]) * inv_n;
+  }
+  if (!active) return;
+#pragma unroll
+  for (int g = 0; g < 2; ++g) rstd[g] = 1.0f / sqrtf(var[g] + p.eps);
+  float a[PC], bb[PC];
+#pragma unroll
+  for (int e = 0; e < PC; ++e) {
+    const int g = (e < split) ? glo : glo + 1;
+    a[e] = (g == 0 ? rstd[0] : rstd[1]) * ga[e];
+    bb[e] = be[e] - (g == 0 ? mean[0] : mean[1]) * a[e];
+  }
+  T* dst = (T*)p.out + (size_t)b * p.HW * C + c0;
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    const int pix = pr + ppi * k;
+    if (pix < p.HW) {
+      float f[PC];
+#pragma unroll
+      for (int e = 0; e < PC; ++e) {
+        float y = to_f32<T>(chunk_elem<T>(raw[k], e)) * a[e] + bb[e];
+        if (p.silu) y = silu_f(y);
+        f[e] = y;
+      }
+      *(uint4*)(dst + (size_t)pix * C) = Chunk<T>::pack(f);
+    }
+  }
+}
+
 // The 64x64 maps in ONE pass with every CU streaming: S workgroups share one (image, block of GB groups whose channels make
 // whole 16-byte vectors), each keeps its HW/S pixels x GB*cpg channels in registers (10 .. 20 vectors per thread), reduces
 // them to per-group (mean, M2) - two passes over registers, torch's arithmetic -, hands the 2*GB numbers to its S-1 partners
@@ -890,10 +1019,20 @@ int run_gn(const GNParams& pin, hipStream_t s) {
       const int ppi = 256 / vpp;
       if ((p.HW + ppi - 1) / ppi > MAXV) continue;
       if ((long)p.B * (p.groups / GB) < 96) continue;          // too few workgroups to fill the chip
-      if (p.HW <= 64 && vpp < 10) continue;                    // 8x8 maps with short runs: gn_small measured faster (8.0 vs 9.7 us)
       p.ty = ppi;
       p.fd_aux = fastdiv_make(vpp);
-      hipLaunchKernelGGL((gn_fused_kernel<T, MAXV>), dim3(p.groups / GB, p.B), dim3(256), 0, s, p, GB);
+      const dim3 grid(p.groups / GB, p.B);
+      const int nv = (p.HW + ppi - 1) / ppi;
+      if (!(g_gn_variant & 4) && nv <= 12) {                   // shipped: one reduction, one barrier (gn_one_kernel); measured at
+        // B = 8: 8x8 x 1280 6.2 -> 4.1 us, 16x16 x 1280 7.9 -> 6.9 us; with more than 12 vectors per thread the two-pass kernel
+        // below is the faster one (16x16 x 1920: 10.2 against 11.4 us)
+        if (nv <= 2) hipLaunchKernelGGL((gn_one_kernel<T, 2>), grid, dim3(256), 0, s, p, GB);
+        else if (nv <= 6) hipLaunchKernelGGL((gn_one_kernel<T, 6>), grid, dim3(256), 0, s, p, GB);
+        else hipLaunchKernelGGL((gn_one_kernel<T, 12>), grid, dim3(256), 0, s, p, GB);
+        return hipGetLastError() == hipSuccess ? 0 : -3;
+      }
+      if (p.HW <= 64 && vpp < 10) continue;                    // 8x8 maps with short runs: gn_small measured faster (8.0 vs 9.7 us)
+      hipLaunchKernelGGL((gn_fused_kernel<T, MAXV>), grid, dim3(256), 0, s, p, GB);
       return hipGetLastError() == hipSuccess ? 0 : -3;
     }
   }

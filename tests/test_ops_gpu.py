@@ -159,6 +159,31 @@ def test_groupnorm_large_mean(L, case):
 
 
 @pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("case", [(8, 1280, 64), (8, 1280, 256), (8, 2560, 64), (8, 640, 1024)])
+def test_groupnorm_outlier_shift_sample(L, dt, case):
+    """The single-launch kernel of the small maps shifts its one-pass sums by the group's first element; when that element
+    is an outlier (here 3e3 standard deviations away, and in a second group a plain large offset) the second moment is
+    taken again around the mean - the result must not depend on what the sample happened to be."""
+    B, Cc, HW = case
+    g = torch.Generator().manual_seed(HW + Cc)
+    x = torch.randn(B, Cc, HW, generator=g)
+    cpg = Cc // 32
+    x[:, 0 * cpg, 0] = 3000.0            # group 0: the shift sample itself is the outlier
+    x[:, 5 * cpg:6 * cpg, :] += 200.0    # group 5: large common offset, ordinary sample
+    x[:, 7 * cpg, 0] = -2500.0
+    gamma = 1 + 0.1 * torch.randn(Cc, generator=g)
+    beta = 0.1 * torch.randn(Cc, generator=g)
+    xin = bf16_round(x) if dt == BF16 else x
+    ref = F.group_norm(xin.double(), 32, gamma.double(), beta.double(), 1e-5).float()
+    out = torch.empty(B, Cc, HW, device="cuda")
+    assert L.lib().ldmseg_op_groupnorm(P(dev(x)), None, P(dev(gamma)), P(dev(beta)), B, Cc, 0, HW, 1e-5, 0, dt, P(out), None) == 0
+    torch.cuda.synchronize()
+    # groups WITHOUT the planted outliers carry the usual tolerance; the planted ones have outputs of ~50 at the outlier
+    # pixel and ~0 elsewhere - compare them against their own scale
+    assert rel_err(out, ref) < (8e-3 if dt == BF16 else 1e-4), case
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
 @pytest.mark.parametrize("case", [
     # B, C, C2, HW, eps, silu
     (2, 320, 0, 256, 1e-5, 1),
@@ -173,8 +198,11 @@ def test_groupnorm_large_mean(L, case):
     (8, 1280, 640, 256, 1e-5, 1),     # concat, cpg = 60: group pairs straddle the source boundary
     (4, 2560, 0, 64, 1e-6, 0),
     (8, 256, 0, 100, 1e-6, 1),        # one vector per pixel, ragged pixel count
+    (8, 1280, 0, 64, 1e-5, 1),        # 8x8 level: 2 vectors per thread
+    (8, 2560, 0, 64, 1e-5, 1),
 ])
-def test_groupnorm(L, dt, case):
+@pytest.mark.parametrize("variant", [0, 4])        # one-pass single-barrier kernel of the small maps / the two-pass one it replaced
+def test_groupnorm(L, dt, case, variant):
     B, Cc, C2, HW, eps, silu = case
     g = torch.Generator().manual_seed(Cc + HW)
     x = torch.randn(B, Cc, HW, generator=g) * 2 + 0.5
@@ -189,7 +217,11 @@ def test_groupnorm(L, dt, case):
         ref = F.silu(ref)
     out = torch.empty(B, Cc + C2, HW, device="cuda")
     dx, dx2, dg, db = dev(x), dev(x2), dev(gamma), dev(beta)
-    r = L.lib().ldmseg_op_groupnorm(P(dx), P(dx2), P(dg), P(db), B, Cc, C2, HW, eps, silu, dt, P(out), None)
+    L.lib().ldmseg_debug_set(8, variant)
+    try:
+        r = L.lib().ldmseg_op_groupnorm(P(dx), P(dx2), P(dg), P(db), B, Cc, C2, HW, eps, silu, dt, P(out), None)
+    finally:
+        L.lib().ldmseg_debug_set(8, 0)
     assert r == 0
     torch.cuda.synchronize()
     assert rel_err(out, ref) < (8e-3 if dt == BF16 else 5e-5), case
