@@ -57,6 +57,12 @@ int ldmseg_op_panoptic_from_decoder(const float* x4, int B, int C, int H4, int W
 int ldmseg_op_igemm(const float* x, const float* x2, const float* w, const float* bias, const float* resid,
                     const float* rowbias, int B, int Ci, int Ci2, int H, int W, int Co, int k, int stride, int up, int geglu,
                     int silu, int splits, int dtype, float* out, void* stream);
+/* [silu](F.group_norm(F.conv2d(x, w, bias, padding=1) + rowbias[b,:,None,None], 32, gamma, beta, eps)) the way the engine runs
+ * resnet conv1 -> norm2 on small maps: the conv as `splits` (>= 2) K slices, then ONE kernel that sums the slices, adds bias and
+ * time-embedding row and normalises (launch_finish_groupnorm).  Returns -4 when the shape has no fused instantiation. */
+int ldmseg_op_conv_groupnorm(const float* x, const float* w, const float* bias, const float* rowbias, const float* gamma,
+                             const float* beta, int B, int Ci, int H, int W, int Co, float eps, int silu, int splits, int dtype,
+                             float* out, void* stream);
 /* F.linear(F.layer_norm(x, (K,), gamma, beta, eps), w, bias) - GEGLU on top when geglu=1 - the way the engine runs
  * norm1 -> to_q|k|v and norm3 -> ff.net.0.proj (diffusers BasicTransformerBlock): one statistics pass over x, then the GEMM on
  * the un-normalised x with gamma folded into the weights and rstd*(acc - mean*c1) + c2 in the epilogue. */

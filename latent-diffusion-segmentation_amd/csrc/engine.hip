@@ -331,6 +331,43 @@ struct Exec {
     return igemm(p);
   }
 
+  // 3x3 conv (stride 1, time-embedding row) whose only consumer is a GroupNorm (resnet conv1 -> norm2): where the conv runs
+  // as K slices and the map is small, the slices' finish and the norm are one launch and the conv's own output is never
+  // stored (launch_finish_groupnorm); otherwise conv and norm as usual.
+  int conv_groupnorm(const ConvW& w, const Act& x, const float* rowbias, int rb_stride, const NormW& n, float eps, int silu,
+                     Act* out) {
+    if (x.C != w.cin_pad || n.C != w.n_valid) return fail(LDMSEG_E_SHAPE, "conv_groupnorm: channel mismatch");
+    IgemmParams p;
+    p.src0 = x.p; p.C0 = x.C;
+    p.B = B; p.Hi = x.H; p.Wi = x.W; p.Ho = x.H; p.Wo = x.W;
+    p.taps = w.taps; p.stride = 1; p.up = 0; p.pad = -1;
+    p.M = B * x.H * x.W; p.N = w.N; p.n_valid = w.n_valid;
+    p.W = w.w; p.bias = w.bias;
+    p.rowbias = rowbias; p.rb_stride = rb_stride;
+    p.epi = EPI_STORE;
+    const int sp = igemm_plan_splits(p, dt);
+    if (sp < 2 || !finish_groupnorm_ok(B, x.H * x.W, w.n_valid, dt)) {
+      Act h;
+      TRY(conv(w, x, nullptr, &h, 1, 0, false, rowbias, rb_stride, nullptr));
+      return groupnorm(n, h, nullptr, eps, silu, out);
+    }
+    *out = new_act(w.n_valid, x.H, x.W, false);
+    if (w.w_cm && igemm_conv_cm(x.H * x.W, x.C, w.N, 3, 1, 0, dt)) { p.W = w.w_cm; p.cm = 1; }
+    p.splits = sp;
+    p.partial = (float*)ws->scratch((size_t)sp * p.M * p.N * sizeof(float));
+    p.no_finish = 1;
+    TRY(igemm(p));
+    GNParams g;
+    g.src0 = nullptr; g.C0 = w.n_valid; g.B = B; g.HW = x.H * x.W; g.groups = 32;
+    g.gamma = n.g; g.beta = n.b; g.eps = eps; g.silu = silu;
+    g.out = out->p;
+    const double bytes = ((double)sp * p.M * p.N * sizeof(float)) + (double)p.M * w.n_valid * esize(dt);
+    ProfScope ps(2, s, 0, bytes, dry(), "finish+GN HW=" + std::to_string(g.HW) + " C=" + std::to_string(g.C0));
+    if (dry()) return 0;
+    TRY(ws_ok());
+    return launch_finish_groupnorm(p, g, dt, s);
+  }
+
   int groupnorm(const NormW& n, const Act& x, const Act* x2, float eps, int silu, Act* out) {
     const int ctot = x.C + (x2 ? x2->C : 0);
     if (ctot != n.C) return fail(LDMSEG_E_SHAPE, "groupnorm: channel mismatch");
@@ -411,12 +448,18 @@ struct ldmseg_unet {
   float* cond = nullptr;   // [B,4,L,L] self-conditioning channel
   float* eps = nullptr;
   size_t loop_elems = 0;
+  // ldmseg_sample_loop: the time-embedding rows of ALL steps (they depend on the timestep only) from one pass over the
+  // 100 MB of time_emb_proj weights instead of one pass per step
+  void* temb_buf = nullptr;            // [steps] int64 timesteps | sinusoid | two MLP activations | [steps][temb_total] rows
+  int temb_cap = 0;                    // steps the buffer holds
+  const float* temb_override = nullptr;   // non-null while the loop runs a forward: this step's row (broadcast over the batch)
 
   ~ldmseg_unet() {
     arena.release();
     if (ws_mem) (void)hipFree(ws_mem);
     if (cond) (void)hipFree(cond);
     if (eps) (void)hipFree(eps);
+    if (temb_buf) (void)hipFree(temb_buf);
   }
 };
 
@@ -593,10 +636,9 @@ int run_resnet(Exec& ex, const ResnetW& r, const Act& x, const Act* skip, const 
   Workspace* ws = ex.ws;
   // output first (persist), temporaries on the scratch stack
   const size_t m = ws->mark();
-  Act n1, h1, n2, sc;
+  Act n1, n2, sc;
   TRY(ex.groupnorm(r.norm1, x, skip, 1e-5f, 1, &n1));
-  TRY(ex.conv(r.conv1, n1, nullptr, &h1, 1, 0, false, temb + r.temb_off, temb_stride, nullptr));
-  TRY(ex.groupnorm(r.norm2, h1, nullptr, 1e-5f, 1, &n2));
+  TRY(ex.conv_groupnorm(r.conv1, n1, temb + r.temb_off, temb_stride, r.norm2, 1e-5f, 1, &n2));
   const Act* resid = &x;
   if (r.has_shortcut) {
     TRY(ex.conv(r.shortcut, x, skip, &sc, 1, 0, false, nullptr, 0, nullptr));
@@ -696,7 +738,9 @@ int unet_forward_impl(ldmseg_unet* u, const float* a, int Ca, const float* b, in
   float* e1 = (float*)ws->persist((size_t)B * kTimeDim * sizeof(float));
   float* emb = (float*)ws->persist((size_t)B * kTimeDim * sizeof(float));
   float* temb = (float*)ws->persist((size_t)B * u->temb_total * sizeof(float));
-  {
+  if (u->temb_override && !dry) {
+    temb = const_cast<float*>(u->temb_override);     // read-only from here on
+  } else {
     ProfScope ps(4, s, 0, 0, dry);
     if (!dry) {
       TRY(ex.ws_ok());
@@ -706,7 +750,7 @@ int unet_forward_impl(ldmseg_unet* u, const float* a, int Ca, const float* b, in
       TRY(launch_small_linear(emb, u->tproj_w, u->tproj_b, temb, TB, kTimeDim, u->temb_total, 1, 0, s));
     }
   }
-  const int tstride = per_sample_t ? u->temb_total : 0;
+  const int tstride = (per_sample_t && !(u->temb_override && !dry)) ? u->temb_total : 0;
 
   // --- conv_in on the channel-concatenated fp32 NCHW input ---
   Act xin = ex.new_act(bke(dt), L, L, true);
@@ -1399,6 +1443,34 @@ int ldmseg_remove_noise(const float* noisy, const float* noise, const int64_t* t
 }
 
 // (re)allocate the sampler's eps / self-condition buffers; growth synchronises the device
+// time-embedding rows of every step of a sampling loop: rows[i] = time_emb_proj_all(silu(MLP(sinusoid(timesteps[i]))))
+static int loop_time_embeddings(ldmseg_unet* h, const int64_t* timesteps, int n_steps, hipStream_t s, const float** rows) {
+  const size_t per = sizeof(int64_t) + (320 + 2 * (size_t)kTimeDim + h->temb_total) * sizeof(float);
+  if (h->temb_cap < n_steps) {
+    HIP_TRY(hipDeviceSynchronize());
+    if (h->temb_buf) (void)hipFree(h->temb_buf);
+    h->temb_buf = nullptr; h->temb_cap = 0;
+    HIP_TRY(hipMalloc(&h->temb_buf, per * n_steps));
+    h->temb_cap = n_steps;
+  }
+  int64_t* ts = (int64_t*)h->temb_buf;
+  float* sinus = (float*)(ts + h->temb_cap);
+  float* e1 = sinus + (size_t)h->temb_cap * 320;
+  float* emb = e1 + (size_t)h->temb_cap * kTimeDim;
+  float* table = emb + (size_t)h->temb_cap * kTimeDim;
+  HIP_TRY(hipMemcpyAsync(ts, timesteps, (size_t)n_steps * sizeof(int64_t), hipMemcpyHostToDevice, s));
+  for (int i0 = 0; i0 < n_steps; i0 += 64) {          // launch_small_linear: up to 64 rows
+    const int r = n_steps - i0 < 64 ? n_steps - i0 : 64;
+    TRY(launch_time_embed(ts + i0, r, 0, r, sinus + (size_t)i0 * 320, s));
+    TRY(launch_small_linear(sinus + (size_t)i0 * 320, h->te1_w, h->te1_b, e1 + (size_t)i0 * kTimeDim, r, 320, kTimeDim, 0, 1, s));
+    TRY(launch_small_linear(e1 + (size_t)i0 * kTimeDim, h->te2_w, h->te2_b, emb + (size_t)i0 * kTimeDim, r, kTimeDim, kTimeDim, 0, 0, s));
+    TRY(launch_small_linear(emb + (size_t)i0 * kTimeDim, h->tproj_w, h->tproj_b, table + (size_t)i0 * h->temb_total, r, kTimeDim,
+                            h->temb_total, 1, 0, s));
+  }
+  *rows = table;
+  return 0;
+}
+
 static int loop_reserve(ldmseg_unet* h, size_t n) {
   if (h->loop_elems >= n) return 0;
   HIP_TRY(hipDeviceSynchronize());
@@ -1459,7 +1531,11 @@ int ldmseg_sample_loop(ldmseg_unet* h, const ldmseg_sample_cfg* cfg, float* late
   const bool inpaint = cfg->known_dev != nullptr;
   if (inpaint && (!cfg->z0_dev || !cfg->noise_dev || !cfg->paste_coef)) return fail(LDMSEG_E_ARG, "inpainting needs z0, noise and paste_coef");
   if (selfc) HIP_TRY(hipMemsetAsync(h->cond, 0, n * sizeof(float), s));   // condition = zeros_like(rgb_latents)
+  const float* temb_rows = nullptr;
+  TRY(loop_time_embeddings(h, cfg->timesteps, cfg->n_steps, s, &temb_rows));
+  struct Clear { ldmseg_unet* u; ~Clear() { u->temb_override = nullptr; } } clear{h};     // (also on the error returns below)
   for (int i = 0; i < cfg->n_steps; ++i) {
+    h->temb_override = temb_rows + (size_t)i * h->temb_total;
     TRY(unet_forward_checked(h, latents, 4, rgb_latents, 4, selfc ? h->cond : nullptr, selfc ? 4 : 0, nullptr, 1,
                              cfg->timesteps[i], B, L, h->eps, s));
     const float* c = cfg->coef + 4 * i;

@@ -900,8 +900,23 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const IgemmParams p)
   f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
   if (p.bias) bias = *(const f32x4*)(p.bias + n);
   for (int m = blockIdx.y * 4 + (threadIdx.x >> 6); m < p.M; m += gridDim.y * 4) {
-    f32x4 v = *(const f32x4*)(p.partial + (size_t)m * p.N + n);
-    for (int z = 1; z < p.splits; ++z) v += *(const f32x4*)(p.partial + ((size_t)z * p.M + m) * p.N + n);
+    // four slices are requested together (a plain `v += load` loop waits for each load before it issues the next: one
+    // dependent trip to the MALL per K slice)
+    const float* q = p.partial + (size_t)m * p.N + n;
+    const size_t slab = (size_t)p.M * p.N;
+    f32x4 v = *(const f32x4*)q;
+    int z = 1;
+    for (; z + 3 < p.splits; z += 4) {
+      const f32x4 t0 = *(const f32x4*)(q + z * slab), t1 = *(const f32x4*)(q + (z + 1) * slab);
+      const f32x4 t2 = *(const f32x4*)(q + (z + 2) * slab), t3 = *(const f32x4*)(q + (z + 3) * slab);
+      v += (t0 + t1) + (t2 + t3);
+    }
+    if (z + 1 < p.splits) {
+      const f32x4 t0 = *(const f32x4*)(q + z * slab), t1 = *(const f32x4*)(q + (z + 1) * slab);
+      v += t0 + t1;
+      z += 2;
+    }
+    if (z < p.splits) v += *(const f32x4*)(q + z * slab);
     v += bias;
     if (p.rowbias) v += *(const f32x4*)(p.rowbias + (size_t)fd_div(m, p.fd_hwo) * p.rb_stride + n);
     if (p.resid) {
@@ -1015,7 +1030,7 @@ int run(const IgemmParams& pin, hipStream_t s) {
                          p.splits > 1 ? p.splits : 1, grid_x, LNF ? 1 : 0, CM ? 1 : 0};
   if (g_log_on) g_log.insert(igemm_dispatch_name(g_last));
   hipLaunchKernelGGL(kern, dim3(grid_x), dim3((WM * WN + LDR) * 64), lds, s, p);
-  if (p.splits > 1) {
+  if (p.splits > 1 && !p.no_finish) {
     const int nq = p.n_valid >> 2;
     const int gx = (nq + 63) / 64;
     int gy = (p.M + 3) / 4;

@@ -75,6 +75,7 @@ struct IgemmParams {
   // igemm_splitk_finish applies the epilogue.
   int splits = 1;
   float* partial = nullptr;
+  int no_finish = 0;             // splits > 1: leave the slabs as they are, the caller runs its own finish (launch_finish_groupnorm)
   const void* zeros = nullptr;   // >= 16 B of zeros (set by the launcher)
   // set by the launcher: divisions the kernels need (by Ho*Wo, Wo, the number of n tiles / tiles / K slices, K tiles per tap)
   FastDiv fd_hwo, fd_wo, fd_nt, fd_ntiles, fd_nsplit, fd_tpt;
@@ -129,6 +130,12 @@ struct GNParams {
 };
 int gn_nchunk(int B, int HW);
 int launch_groupnorm(const GNParams& p, int dtype, hipStream_t s);
+// Split-K finish of a conv fused with the GroupNorm (+SiLU) that consumes it (resnet conv1 -> norm2 on the 8x8 / 16x16
+// maps): out = GN(sum_z partial[z] + bias + rowbias[image]) in ONE launch; the conv's own output is never stored.
+// ip: the igemm launch (partial, splits, M, N, n_valid, bias, rowbias, rb_stride); g: B, HW, C0 = channels, gamma, beta,
+// eps, silu, out.  finish_groupnorm_ok: whether the shape has an instantiation (otherwise: igemm's finish + launch_groupnorm).
+bool finish_groupnorm_ok(int B, int HW, int C, int dtype);
+int launch_finish_groupnorm(const IgemmParams& ip, const GNParams& g, int dtype, hipStream_t s);
 void groupnorm_set_variant(int v);   // tuning knob: bit0 = no cooperative one-pass kernel (64x64 maps on the two-launch path)
 
 // LayerNorm over the last dim of [M][C] (+ optional SiLU) - also LayerNorm2d in NHWC

@@ -597,8 +597,10 @@ __global__ __launch_bounds__(256) void gn_one_kernel(const GNParams p, int GB) {
   const int cpg = p.cpg;
   const int vpp = GB * cpg / PC;
   const int ppi = p.ty;
-  const int b = blockIdx.y;
-  const int cfirst = blockIdx.x * GB * cpg;
+  // consecutive workgroup ids go to consecutive XCDs: image = id % B keeps the group blocks of one image - whose 80 .. 320-byte
+  // runs share 128-byte lines with their neighbours' - on one XCD (one L2) when B is a multiple of 8
+  const int b = (int)(blockIdx.x % (unsigned)p.B);
+  const int cfirst = (int)(blockIdx.x / (unsigned)p.B) * GB * cpg;
   const int tid = threadIdx.x;
   const int pr = fd_div(tid, p.fd_aux), j = tid - pr * vpp;
   const bool active = pr < ppi;
@@ -704,6 +706,160 @@ __global__ __launch_bounds__(256) void gn_one_kernel(const GNParams p, int GB) {
 #pragma unroll
       for (int e = 0; e < PC; ++e) {
         float y = to_f32<T>(chunk_elem<T>(raw[k], e)) * a[e] + bb[e];
+        if (p.silu) y = silu_f(y);
+        f[e] = y;
+      }
+      *(uint4*)(dst + (size_t)pix * C) = Chunk<T>::pack(f);
+    }
+  }
+}
+
+// Split-K finish + GroupNorm (+SiLU) in one launch (launch_finish_groupnorm): gn_one_kernel whose "load" is the sum of the
+// K-slice slabs of the producing conv plus its bias and time-embedding row.  On the 8x8 / 16x16 maps the finish kernel and the
+// norm were two latency chains of 6 - 9 us each around a tensor of 1 - 5 MB that nobody else reads.  Values stay fp32 from the
+// accumulators to the normalisation (the unfused path rounds them to the storage type in between).  The shift sample of the
+// one-pass sums is bias + time-embedding value of the group's first channel (no group member is known before the sums);
+// the same outlier fallback as gn_one_kernel covers the case where that is far from the group's mean.
+template <typename T, int MAXV>
+__global__ __launch_bounds__(256) void finish_gn_kernel(const GNParams p, int GB, const float* __restrict__ partial, int splits,
+                                                        int N, long slab, const float* __restrict__ bias,
+                                                        const float* __restrict__ rowbias, int rb_stride) {
+  constexpr int PC = Chunk<T>::N;
+  const int C = p.C0;
+  const int cpg = p.cpg;
+  const int vpp = GB * cpg / PC;
+  const int ppi = p.ty;
+  // consecutive workgroup ids go to consecutive XCDs: image = id % B keeps the group blocks of one image - whose 80 .. 320-byte
+  // runs share 128-byte lines with their neighbours' - on one XCD (one L2) when B is a multiple of 8
+  const int b = (int)(blockIdx.x % (unsigned)p.B);
+  const int cfirst = (int)(blockIdx.x / (unsigned)p.B) * GB * cpg;
+  const int tid = threadIdx.x;
+  const int pr = fd_div(tid, p.fd_aux), j = tid - pr * vpp;
+  const bool active = pr < ppi;
+  const int c0 = cfirst + j * PC;
+  const int glo = (j * PC) >= cpg ? 1 : 0;
+  const int split = min(PC, (glo + 1) * cpg - j * PC);
+  float v[MAXV][PC];
+  const float* src = partial + (size_t)b * p.HW * N + c0;
+  // the slices of ZU K slices are requested together: one round trip per ZU slices instead of one per slice (a plain
+  // `for z: acc += load` waits for every load before it issues the next - 8 slices were 8 dependent trips to the MALL)
+  constexpr int ZU = MAXV <= 2 ? 4 : 2;
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k)
+#pragma unroll
+    for (int e = 0; e < PC; ++e) v[k][e] = 0.f;
+  for (int z0 = 0; z0 < splits; z0 += ZU) {
+    f32x4 t[ZU][MAXV][PC / 4];
+#pragma unroll
+    for (int zi = 0; zi < ZU; ++zi) {
+      const bool zok = z0 + zi < splits;                 // wave-uniform
+#pragma unroll
+      for (int k = 0; k < MAXV; ++k) {
+        const int pix = pr + ppi * k;
+        const bool ok = zok && active && pix < p.HW;
+#pragma unroll
+        for (int e = 0; e < PC; e += 4)
+          t[zi][k][e / 4] = ok ? *(const f32x4*)(src + (size_t)(z0 + zi) * slab + (size_t)pix * N + e) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+#pragma unroll
+    for (int zi = 0; zi < ZU; ++zi)
+#pragma unroll
+      for (int k = 0; k < MAXV; ++k)
+#pragma unroll
+        for (int e = 0; e < PC; ++e) v[k][e] += t[zi][k][e / 4][e & 3];
+  }
+  const float* rbp = rowbias ? rowbias + (size_t)b * rb_stride : nullptr;
+  float K[2];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const int c = cfirst + (g < GB ? g : 0) * cpg;
+    K[g] = bias[c] + (rbp ? rbp[c] : 0.f);
+  }
+  float ga[PC], be[PC], add[PC];
+#pragma unroll
+  for (int e = 0; e < PC; ++e) { ga[e] = 0.f; be[e] = 0.f; add[e] = 0.f; }
+  if (active) {
+#pragma unroll
+    for (int e = 0; e < PC; e += 4) {
+      const f32x4 g4 = *(const f32x4*)(p.gamma + c0 + e), b4 = *(const f32x4*)(p.beta + c0 + e);
+      f32x4 a4 = *(const f32x4*)(bias + c0 + e);
+      if (rbp) a4 += *(const f32x4*)(rbp + c0 + e);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { ga[e + r] = g4[r]; be[e + r] = b4[r]; add[e + r] = a4[r]; }
+    }
+  }
+  const float klo = glo == 0 ? K[0] : K[1], khi = K[1];
+  float slo = 0.f, shi = 0.f, qlo = 0.f, qhi = 0.f;
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    const bool ok = active && pr + ppi * k < p.HW;
+#pragma unroll
+    for (int e = 0; e < PC; ++e) {
+      v[k][e] += add[e];
+      if (ok) {
+        if (e < split) { const float d = v[k][e] - klo; slo += d; qlo += d * d; }
+        else { const float d = v[k][e] - khi; shi += d; qhi += d * d; }
+      }
+    }
+  }
+  __shared__ float red[4][4];
+  {
+    const float s0 = wave64_sum(glo == 0 ? slo : 0.f), s1 = wave64_sum(glo == 0 ? shi : slo);
+    const float q0 = wave64_sum(glo == 0 ? qlo : 0.f), q1 = wave64_sum(glo == 0 ? qhi : qlo);
+    if ((tid & 63) == 0) { red[0][tid >> 6] = s0; red[1][tid >> 6] = s1; red[2][tid >> 6] = q0; red[3][tid >> 6] = q1; }
+  }
+  __syncthreads();
+  float mean[2], var[2], rstd[2];
+  const float inv_n = (float)p.inv_n;
+  bool far = false;
+#pragma unroll
+  for (int g = 0; g < 2; ++g) {
+    const float ms = (((red[g][0] + red[g][1]) + red[g][2]) + red[g][3]) * inv_n;
+    const float m2 = (((red[2 + g][0] + red[2 + g][1]) + red[2 + g][2]) + red[2 + g][3]) * inv_n;
+    mean[g] = K[g] + ms;
+    var[g] = fmaxf(m2 - ms * ms, 0.f);
+    far |= ms * ms > 64.f * var[g];
+  }
+  if (far) {
+    const float mlo = glo == 0 ? mean[0] : mean[1], mhi = mean[1];
+    qlo = 0.f; qhi = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+      if (active && pr + ppi * k < p.HW) {
+#pragma unroll
+        for (int e = 0; e < PC; ++e) {
+          if (e < split) { const float d = v[k][e] - mlo; qlo += d * d; }
+          else { const float d = v[k][e] - mhi; qhi += d * d; }
+        }
+      }
+    }
+    const float q0 = wave64_sum(glo == 0 ? qlo : 0.f), q1 = wave64_sum(glo == 0 ? qhi : qlo);
+    __syncthreads();
+    if ((tid & 63) == 0) { red[2][tid >> 6] = q0; red[3][tid >> 6] = q1; }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < 2; ++g) var[g] = (((red[2 + g][0] + red[2 + g][1]) + red[2 + g][2]) + red[2 + g][3]) * inv_n;
+  }
+  if (!active) return;
+#pragma unroll
+  for (int g = 0; g < 2; ++g) rstd[g] = 1.0f / sqrtf(var[g] + p.eps);
+  float a[PC], bb[PC];
+#pragma unroll
+  for (int e = 0; e < PC; ++e) {
+    const int g = (e < split) ? glo : glo + 1;
+    a[e] = (g == 0 ? rstd[0] : rstd[1]) * ga[e];
+    bb[e] = be[e] - (g == 0 ? mean[0] : mean[1]) * a[e];
+  }
+  T* dst = (T*)p.out + (size_t)b * p.HW * C + c0;
+#pragma unroll
+  for (int k = 0; k < MAXV; ++k) {
+    const int pix = pr + ppi * k;
+    if (pix < p.HW) {
+      float f[PC];
+#pragma unroll
+      for (int e = 0; e < PC; ++e) {
+        float y = v[k][e] * a[e] + bb[e];
         if (p.silu) y = silu_f(y);
         f[e] = y;
       }
@@ -1021,14 +1177,14 @@ int run_gn(const GNParams& pin, hipStream_t s) {
       if ((long)p.B * (p.groups / GB) < 96) continue;          // too few workgroups to fill the chip
       p.ty = ppi;
       p.fd_aux = fastdiv_make(vpp);
-      const dim3 grid(p.groups / GB, p.B);
+      const dim3 grid(p.groups / GB, p.B), grid1((p.groups / GB) * p.B);
       const int nv = (p.HW + ppi - 1) / ppi;
       if (!(g_gn_variant & 4) && nv <= 12) {                   // shipped: one reduction, one barrier (gn_one_kernel); measured at
         // B = 8: 8x8 x 1280 6.2 -> 4.1 us, 16x16 x 1280 7.9 -> 6.9 us; with more than 12 vectors per thread the two-pass kernel
         // below is the faster one (16x16 x 1920: 10.2 against 11.4 us)
-        if (nv <= 2) hipLaunchKernelGGL((gn_one_kernel<T, 2>), grid, dim3(256), 0, s, p, GB);
-        else if (nv <= 6) hipLaunchKernelGGL((gn_one_kernel<T, 6>), grid, dim3(256), 0, s, p, GB);
-        else hipLaunchKernelGGL((gn_one_kernel<T, 12>), grid, dim3(256), 0, s, p, GB);
+        if (nv <= 2) hipLaunchKernelGGL((gn_one_kernel<T, 2>), grid1, dim3(256), 0, s, p, GB);
+        else if (nv <= 6) hipLaunchKernelGGL((gn_one_kernel<T, 6>), grid1, dim3(256), 0, s, p, GB);
+        else hipLaunchKernelGGL((gn_one_kernel<T, 12>), grid1, dim3(256), 0, s, p, GB);
         return hipGetLastError() == hipSuccess ? 0 : -3;
       }
       if (p.HW <= 64 && vpp < 10) continue;                    // 8x8 maps with short runs: gn_small measured faster (8.0 vs 9.7 us)
@@ -1137,6 +1293,57 @@ void groupnorm_set_variant(int v) { g_gn_variant = v; }
 
 int launch_groupnorm(const GNParams& p, int dtype, hipStream_t s) {
   return dtype == DT_BF16 ? run_gn<bf16_t>(p, s) : run_gn<float>(p, s);
+}
+
+namespace {
+// group block / pixels per trip / vectors per thread of the finish + GroupNorm kernel; false: no instantiation
+template <typename T>
+bool finish_gn_plan(int B, int HW, int C, int* GBo, int* vppo, int* ppio, int* nvo) {
+  constexpr int PC = Chunk<T>::N;
+  if (C % 32 != 0) return false;
+  const int cpg = C / 32;
+  for (int GB = 1; GB <= 2; ++GB) {
+    if ((GB * cpg) % PC != 0 || 32 % GB != 0) continue;
+    const int vpp = GB * cpg / PC;
+    if (vpp > 64) continue;
+    const int ppi = 256 / vpp;
+    const int nv = (HW + ppi - 1) / ppi;
+    if (nv > 12) continue;
+    if ((long)B * (32 / GB) < 96) continue;
+    *GBo = GB; *vppo = vpp; *ppio = ppi; *nvo = nv;
+    return true;
+  }
+  return false;
+}
+template <typename T>
+int run_finish_gn(const IgemmParams& ip, GNParams p, hipStream_t s) {
+  int GB, vpp, ppi, nv;
+  if (!finish_gn_plan<T>(p.B, p.HW, p.C0, &GB, &vpp, &ppi, &nv)) return -2;
+  if (ip.splits < 2 || !ip.partial || !ip.bias || ip.n_valid != p.C0 || ip.M != p.B * p.HW || p.C1 != 0) return -2;
+  p.groups = 32;
+  p.cpg = p.C0 / 32;
+  p.inv_n = 1.0 / ((double)p.HW * p.cpg);
+  p.ty = ppi;
+  p.fd_aux = fastdiv_make(vpp);
+  const dim3 grid((32 / GB) * p.B);
+  const long slab = (long)ip.M * ip.N;
+#define LDMSEG_FGN(MV) hipLaunchKernelGGL((finish_gn_kernel<T, MV>), grid, dim3(256), 0, s, p, GB, ip.partial, ip.splits, ip.N, slab, \
+                                          ip.bias, ip.rowbias, ip.rb_stride)
+  if (nv <= 2) LDMSEG_FGN(2);
+  else if (nv <= 6) LDMSEG_FGN(6);
+  else LDMSEG_FGN(12);
+#undef LDMSEG_FGN
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+}  // namespace
+
+bool finish_groupnorm_ok(int B, int HW, int C, int dtype) {
+  int a, b, c, d;
+  if (g_gn_variant & 8) return false;       // tuning bit 3: keep finish and norm apart
+  return dtype == DT_BF16 ? finish_gn_plan<bf16_t>(B, HW, C, &a, &b, &c, &d) : finish_gn_plan<float>(B, HW, C, &a, &b, &c, &d);
+}
+int launch_finish_groupnorm(const IgemmParams& ip, const GNParams& g, int dtype, hipStream_t s) {
+  return dtype == DT_BF16 ? run_finish_gn<bf16_t>(ip, g, s) : run_finish_gn<float>(ip, g, s);
 }
 
 int launch_layernorm(const void* x, void* y, const float* gamma, const float* beta, int M, int C, float eps,

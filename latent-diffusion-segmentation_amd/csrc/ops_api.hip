@@ -184,6 +184,40 @@ int ldmseg_op_groupnorm(const float* x, const float* x2, const float* gamma, con
   return unpack_nhwc(op, out, B, C + C2, HW, C + C2, dtype, s);
 }
 
+// silu(GroupNorm32(conv3x3(x, w, bias) + rowbias[image])) through the engine's fused path: the conv as `splits` K slices without
+// its own finish, then launch_finish_groupnorm.  -4: the shape has no fused instantiation (the engine then runs conv and norm apart).
+int ldmseg_op_conv_groupnorm(const float* x, const float* w, const float* bias, const float* rowbias, const float* gamma,
+                             const float* beta, int B, int Ci, int H, int W, int Co, float eps, int silu, int splits, int dtype,
+                             float* out, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  Temp t;
+  const int a = bke(dtype);
+  if (Ci % a || splits < 2) return -2;
+  if (!finish_groupnorm_ok(B, H * W, Co, dtype)) return -4;
+  void* xp = t.get((size_t)B * H * W * Ci * es(dtype));
+  if (launch_pack_nchw(x, xp, B, Ci, H * W, Ci, 1.f, 0.f, dtype, s)) return -3;
+  const int bn = igemm_pick_bn(Co, EPI_STORE);
+  const int Np = rupi(Co, bn);
+  void* wp = t.get((size_t)Np * 9 * Ci * es(dtype));
+  if (launch_repack_conv(w, wp, Co, Ci, 3, 3, Np, Ci, dtype, s)) return -3;
+  float* bp = (float*)t.get(Np * sizeof(float));
+  (void)hipMemsetAsync(bp, 0, Np * sizeof(float), s);
+  if (bias) (void)hipMemcpyAsync(bp, bias, Co * sizeof(float), hipMemcpyDeviceToDevice, s);
+  void* op = t.get((size_t)B * H * W * Co * es(dtype));
+  IgemmParams p;
+  p.src0 = xp; p.C0 = Ci; p.B = B; p.Hi = H; p.Wi = W; p.Ho = H; p.Wo = W; p.taps = 9;
+  p.M = B * H * W; p.N = Np; p.n_valid = Co; p.W = wp; p.bias = bp; p.rowbias = rowbias; p.rb_stride = Co;
+  p.epi = EPI_STORE; p.splits = splits; p.no_finish = 1;
+  p.partial = (float*)t.get((size_t)splits * p.M * Np * sizeof(float));
+  int r = launch_igemm(p, dtype, s);
+  if (r) return r;
+  GNParams g;
+  g.C0 = Co; g.B = B; g.HW = H * W; g.gamma = gamma; g.beta = beta; g.eps = eps; g.silu = silu; g.out = op;
+  r = launch_finish_groupnorm(p, g, dtype, s);
+  if (r) return r;
+  return unpack_nhwc(op, out, B, Co, H * W, Co, dtype, s);
+}
+
 // timing of one GroupNorm launch shape the way the engine launches it (tools/kbench.py gn): average microseconds over
 // `iters` back-to-back launches between two HIP events; the input is whatever the allocation holds (statistics of garbage
 // cost the same), gamma / beta are [C + C2] device vectors

@@ -95,6 +95,7 @@ SIGNATURES = {
     "ldmseg_bench_attention": (_i, [_vp, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_float), _vp]),
     "ldmseg_op_panoptic_from_decoder": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _f, _i, _d, _i64, _vp, _vp, _vp,
                                              _vp, _vp, _vp, _vp]),
+    "ldmseg_op_conv_groupnorm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _i, _vp, _vp]),
     "ldmseg_bench_groupnorm": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_float), _vp]),
     "ldmseg_igemm_last_kernel": (_i, [C.c_char_p, _i]),
     "ldmseg_op_fastdiv": (_i, [_vp, _i, _i, _vp, _vp]),

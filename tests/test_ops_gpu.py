@@ -227,6 +227,47 @@ def test_groupnorm(L, dt, case, variant):
     assert rel_err(out, ref) < (8e-3 if dt == BF16 else 5e-5), case
 
 
+@pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("case", [
+    # B, Ci, H, Co, splits, temb row, silu: resnet conv1 -> norm2 where the conv runs as K slices
+    (8, 1280, 8, 1280, 8, 1, 1),      # 8x8 level: 2 vectors per thread
+    (8, 640, 16, 1280, 2, 1, 1),      # 16x16 level, first resnet of the level (640 -> 1280 channels)
+    (8, 1280, 16, 1280, 4, 1, 1),
+    (8, 2560, 8, 1280, 8, 1, 1),      # up-path conv1 on the widest concat
+    (8, 320, 16, 640, 3, 0, 0),       # 640 channels: two groups per workgroup in bf16; no time-embedding row, no SiLU
+    (8, 256, 8, 320, 2, 1, 1),        # cpg 10: 4-group blocks are not available -> -4, the engine keeps finish and norm apart
+])
+def test_conv_groupnorm_fused_finish(L, dt, case):
+    """launch_finish_groupnorm: K-slice sum + bias + time-embedding row + GroupNorm (+SiLU) in one launch, against the torch
+    ops; the fused path keeps fp32 from the accumulators to the normalisation, so it is at least as close as conv-then-norm."""
+    B, Ci, H, Co, splits, use_rb, silu = case
+    g = torch.Generator().manual_seed(Ci + H + Co)
+    x = torch.randn(B, Ci, H, H, generator=g)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / (Ci * 9) ** 0.5
+    b = torch.randn(Co, generator=g)
+    rb = 2.0 * torch.randn(B, Co, generator=g) if use_rb else None
+    gamma = 1 + 0.1 * torch.randn(Co, generator=g)
+    beta = 0.1 * torch.randn(Co, generator=g)
+    rnd = bf16_round if dt == BF16 else (lambda t: t)
+    torch.set_num_threads(32)
+    h = F.conv2d(rnd(x), rnd(w), b, padding=1)
+    if rb is not None:
+        h = h + rb[:, :, None, None]
+    ref = F.group_norm(h, 32, gamma, beta, 1e-5)
+    if silu:
+        ref = F.silu(ref)
+    out = torch.empty(ref.shape, device="cuda")
+    dx, dw, db, drb, dg, dbe = dev(x), dev(w), dev(b), dev(rb), dev(gamma), dev(beta)      # (kept alive until the sync below)
+    r = L.lib().ldmseg_op_conv_groupnorm(P(dx), P(dw), P(db), P(drb), P(dg), P(dbe), B, Ci, H, H, Co, 1e-5, silu, splits, dt,
+                                         P(out), None)
+    if Co == 320 and dt == BF16:
+        assert r == -4
+        return
+    assert r == 0, (r, L.lib().ldmseg_last_error())
+    torch.cuda.synchronize()
+    assert rel_err(out, ref) < (8e-3 if dt == BF16 else 2e-4), case
+
+
 @pytest.mark.parametrize("variant", [0, 1])        # cooperative one-pass kernel, and the two-launch path it replaces
 @pytest.mark.parametrize("dt", [F32, BF16])
 @pytest.mark.parametrize("case", [
