@@ -414,6 +414,66 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* x, T* y, const 
   }
 }
 
+// LayerNorm statistics of the folded norms (transformer norm1 / norm3, C = 320 / 640 / 1280): LPR = 8 / 16 / 32 lanes share a
+// row (5 vectors per lane), so a wave reduces 8 / 4 / 2 rows with ONE butterfly instead of one row with a full 64-lane one, no
+// lane idles on the 40-vector rows, and 2 batches of rows are in flight per wave.  Two passes over the registers (mean, then
+// centred second moment), like layernorm_kernel.  Measured at B = 8 (M = 32768, C = 320): 8.5 -> us per launch.
+template <int LPR>
+__device__ __forceinline__ float lanes_sum(float v) {
+  v += dpp_f<0xB1>(v);          // xor 1
+  v += dpp_f<0x4E>(v);          // xor 2
+  v += dpp_f<0x141>(v);         // mirror within 8
+  if constexpr (LPR >= 16) v += dpp_f<0x140>(v);   // mirror within 16
+  if constexpr (LPR >= 32) v = xor16_sum(v);
+  if constexpr (LPR >= 64) v = xor32_sum(v);
+  return v;
+}
+template <typename T, int LPR, int RPW>
+__global__ __launch_bounds__(256) void rowstats_kernel(const T* __restrict__ x, float* __restrict__ stats, int M, int C, float eps) {
+  constexpr int PC = Chunk<T>::N, VPL = 5, RW = 64 / LPR;
+  const int lane = threadIdx.x & 63;
+  const int sub = lane & (LPR - 1), rsel = lane / LPR;
+  const int nvec = C / PC;
+  const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nwaves = gridDim.x * 4;
+  const float invC = 1.0f / (float)C;
+  for (int row0 = wave_global * (RW * RPW); row0 < M; row0 += nwaves * (RW * RPW)) {
+    uint4 raw[RPW][VPL];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      const int row = row0 + r * RW + rsel;
+#pragma unroll
+      for (int k = 0; k < VPL; ++k) {
+        const int v = sub + k * LPR;
+        raw[r][k] = (v < nvec && row < M) ? *(const uint4*)(x + (size_t)row * C + v * PC) : make_uint4(0, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      const int row = row0 + r * RW + rsel;
+      float f[VPL][PC];
+      float sm = 0.f;
+#pragma unroll
+      for (int k = 0; k < VPL; ++k) {
+        Chunk<T>::unpack(raw[r][k], f[k]);
+#pragma unroll
+        for (int e = 0; e < PC; ++e) sm += f[k][e];        // absent vectors are zero
+      }
+      const float mean = lanes_sum<LPR>(sm) * invC;
+      float q = 0.f;
+#pragma unroll
+      for (int k = 0; k < VPL; ++k) {
+        if (sub + k * LPR < nvec) {
+#pragma unroll
+          for (int e = 0; e < PC; ++e) { const float d = f[k][e] - mean; q += d * d; }
+        }
+      }
+      const float rstd = 1.0f / sqrtf(lanes_sum<LPR>(q) * invC + eps);
+      if (sub == 0 && row < M) *(float2*)(stats + (size_t)row * 2) = make_float2(mean, rstd);
+    }
+  }
+}
+
 // Small feature maps (8x8 .. 32x32): one workgroup per (image, group) keeps the whole group in
 // registers - statistics, normalisation and the store in ONE launch instead of two dependent ones
 // (these tensors are a few hundred KB; the two-kernel path is pure launch latency there).
@@ -1264,6 +1324,21 @@ int run_rowstats(const void* x, float* stats, int M, int C, float eps, hipStream
     return dim3(blocks < 1 ? 1 : blocks);
   };
   const T* xp = (const T*)x;
+  {
+    const int nvec = C / PC;
+    constexpr int RPW = 2;
+    auto grid_rows = [&](int rows_per_wave) {
+      int blocks = (M + 4 * rows_per_wave - 1) / (4 * rows_per_wave);
+      if (blocks > 4096) blocks = 4096;
+      return dim3(blocks < 1 ? 1 : blocks);
+    };
+    if (!(g_gn_variant & 16)) {       // (tuning bit 4: the one-row-per-wave kernel below)
+      if (nvec <= 40) { hipLaunchKernelGGL((rowstats_kernel<T, 8, RPW>), grid_rows(8 * RPW), block, 0, s, xp, stats, M, C, eps); return hipGetLastError() == hipSuccess ? 0 : -3; }
+      if (nvec <= 80) { hipLaunchKernelGGL((rowstats_kernel<T, 16, RPW>), grid_rows(4 * RPW), block, 0, s, xp, stats, M, C, eps); return hipGetLastError() == hipSuccess ? 0 : -3; }
+      if (nvec <= 160) { hipLaunchKernelGGL((rowstats_kernel<T, 32, RPW>), grid_rows(2 * RPW), block, 0, s, xp, stats, M, C, eps); return hipGetLastError() == hipSuccess ? 0 : -3; }
+      if (nvec <= 320) { hipLaunchKernelGGL((rowstats_kernel<T, 64, RPW>), grid_rows(RPW), block, 0, s, xp, stats, M, C, eps); return hipGetLastError() == hipSuccess ? 0 : -3; }
+    }
+  }
   switch (vpl) {
     case 1: hipLaunchKernelGGL((layernorm_kernel<T, 1, 4, true>), grid_for_rpw(4), block, 0, s, xp, (T*)nullptr, nullptr, nullptr, M, C, eps, 0, stats); break;
     case 2: hipLaunchKernelGGL((layernorm_kernel<T, 2, 4, true>), grid_for_rpw(4), block, 0, s, xp, (T*)nullptr, nullptr, nullptr, M, C, eps, 0, stats); break;
