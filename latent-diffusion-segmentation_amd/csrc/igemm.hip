@@ -1054,7 +1054,11 @@ inline bool mid8_ok(long t128, int splits) {
 //   2  256 rows, 8 waves, plain K loop           5  128 rows, 4 waves, 4-stage ring (one workgroup per CU)
 //   6  64 rows, 4 waves, 4-stage ring            7  64 rows, 4 waves, two workgroups per CU
 //   8  128 rows, 4 waves, two workgroups per CU  9  64 rows, 8 waves (16 x 80 wave tiles), 4-stage ring
-constexpr int kNumCfg = 10;
+//   10 / 11  64 rows, 4 compute (32 x 80 wave tiles) + 4 loader waves, 4- / 3-stage ring: the M = 512 .. 2048 1x1 launches.
+//      (entry 9 re-reads the W fragments in each of its four wave rows - 98 KB of fragment reads per K tile against 56 KB here -
+//      and its compute waves issue the LDS-DMA themselves: phase ablation of M = 2048, N = K = 1280 showed DMA issue, fragment
+//      reads + MFMA, epilogue and launch skeleton ADDING UP, 4 + 5 + 2 + 5 us; with loader waves 17.0 -> 13.6 us)
+constexpr int kNumCfg = 12;
 template <typename T, int BN, bool LNF>
 int run_cfg(int cfg, const IgemmParams& p, hipStream_t s) {
   switch (cfg) {
@@ -1068,6 +1072,8 @@ int run_cfg(int cfg, const IgemmParams& p, hipStream_t s) {
   }
   if constexpr (!LNF) {
     if (cfg == 9) return run<T, 64, BN, 4, 2, 4>(p, s);
+    if (cfg == 10) return run<T, 64, BN, 2, 2, 4, true, 4>(p, s);
+    if (cfg == 11) return run<T, 64, BN, 2, 2, 3, true, 4>(p, s);
     switch (cfg) {
       case 2: return run<T, 256, BN, 4, 2, 3, false>(p, s);
       case 3: return run<T, 128, BN, 2, 2, 4, true, 4>(p, s);

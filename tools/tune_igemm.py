@@ -3,6 +3,7 @@
 (csrc/igemm_tuned.inc) the dispatcher consults.  Tuning tool: run on the MI355X, product code never calls it.
 
     python tools/tune_igemm.py [B=8] [L=64] [dtype=bf16] > gpurun_out/tune_B8_L64.log     # table -> gpurun_out/tuned_B8_L64_bf16.inc
+    CFGS=10,11 python tools/tune_igemm.py ...      # only these entries of the instantiation list against the current dispatch
 
 Timing: ldmseg_bench_igemm (HIP events around back-to-back launches) with the layer's weights rotated over enough copies to
 come from HBM like they do in the real forward (1.6 GB of weights per step); activations stay cache-warm, as they are
@@ -25,7 +26,8 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 LAT = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 DTN = sys.argv[3] if len(sys.argv) > 3 else "bf16"
 DT = {"bf16": 1, "fp32": 0}[DTN]
-NCFG = 10
+NCFG = 12
+CFGS = [int(c) for c in os.environ["CFGS"].split(",")] if os.environ.get("CFGS") else list(range(NCFG))   # subset to try
 ITERS = 30
 
 
@@ -68,11 +70,11 @@ for case in SHAPES:
     h_us, h_name = bench(t, -1, 0, ln)
     best = (h_us, -1, 0, h_name)
     rows = []
-    for cfg in range(NCFG):
+    for cfg in CFGS:
         for sp in (1, 2, 3, 4, 6, 8, 12, 16):
             if sp > 1 and (geglu or ln or nk // sp < 6):
                 continue
-            bm = 256 if cfg < 3 else (128 if cfg in (3, 4, 5, 8) else 64)   # (6, 7, 9: 64 rows)
+            bm = 256 if cfg < 3 else (128 if cfg in (3, 4, 5, 8) else 64)   # (6, 7, 9, 10, 11: 64 rows)
             items = ((M + bm - 1) // bm) * (Co // (128 if geglu else 160 if Co % 160 == 0 else 128)) * sp
             if sp > 1 and items > 1400:
                 continue
