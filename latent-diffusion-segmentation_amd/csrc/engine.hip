@@ -1447,11 +1447,14 @@ int ldmseg_remove_noise(const float* noisy, const float* noise, const int64_t* t
 static int loop_time_embeddings(ldmseg_unet* h, const int64_t* timesteps, int n_steps, hipStream_t s, const float** rows) {
   const size_t per = sizeof(int64_t) + (320 + 2 * (size_t)kTimeDim + h->temb_total) * sizeof(float);
   if (h->temb_cap < n_steps) {
+    // room for at least 64 steps (6 MB) so that a short warm-up call followed by a longer run does not re-allocate
+    int cap = 64;
+    while (cap < n_steps) cap *= 2;
     HIP_TRY(hipDeviceSynchronize());
     if (h->temb_buf) (void)hipFree(h->temb_buf);
     h->temb_buf = nullptr; h->temb_cap = 0;
-    HIP_TRY(hipMalloc(&h->temb_buf, per * n_steps));
-    h->temb_cap = n_steps;
+    HIP_TRY(hipMalloc(&h->temb_buf, per * cap));
+    h->temb_cap = cap;
   }
   int64_t* ts = (int64_t*)h->temb_buf;
   float* sinus = (float*)(ts + h->temb_cap);

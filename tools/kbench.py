@@ -102,7 +102,7 @@ if __name__ == "__main__":
         from test_igemm_shapes_gpu import SHAPES
         tot_us = tot_fl = 0.0
         for c in SHAPES:
-            u, f = igemm(c, dt)
+            u, f = igemm(c, dt, B=int(os.environ.get("B", 8)))
             tot_us += u
             tot_fl += f
         print(f"sum over distinct shapes: {tot_us:.1f} us, {tot_fl / tot_us / 1e6:.1f} TF/s")
