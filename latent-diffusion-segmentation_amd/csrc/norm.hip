@@ -417,7 +417,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* x, T* y, const 
 // LayerNorm statistics of the folded norms (transformer norm1 / norm3, C = 320 / 640 / 1280): LPR = 8 / 16 / 32 lanes share a
 // row (5 vectors per lane), so a wave reduces 8 / 4 / 2 rows with ONE butterfly instead of one row with a full 64-lane one, no
 // lane idles on the 40-vector rows, and 2 batches of rows are in flight per wave.  Two passes over the registers (mean, then
-// centred second moment), like layernorm_kernel.  Measured at B = 8 (M = 32768, C = 320): 8.5 -> us per launch.
+// centred second moment), like layernorm_kernel.  Measured at B = 8: 187 -> 172 us per forward over the 32 launches.
 template <int LPR>
 __device__ __forceinline__ float lanes_sum(float v) {
   v += dpp_f<0xB1>(v);          // xor 1
