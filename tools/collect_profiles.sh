@@ -23,7 +23,7 @@ python bench.py --batch 4 --latent 128 --steps 20 --warmup 2 --no-cpu-baseline -
 python bench.py --batch 4 --latent 128 --steps 20 --warmup 2 --attention-fp8 16384 --no-cpu-baseline --no-extras --no-images > $O/bench_config4_b4_l128_fp8attn.json 2>/dev/null
 python tools/kbench.py gn > $O/kbench_groupnorm.txt 2>&1
 python tools/kbench.py attn > $O/kbench_attention.txt 2>&1
-for u in mfma_lds mfma_lds2 buf_lds valu_trans copy_floor; do [ -x tools/ubench/bin/$u ] && timeout 300 tools/ubench/bin/$u > $O/ubench_$u.txt 2>&1; done
+for u in mfma_lds mfma_lds2 buf_lds valu_trans copy_floor launch_floor; do [ -x tools/ubench/bin/$u ] && timeout 300 tools/ubench/bin/$u > $O/ubench_$u.txt 2>&1; done
 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; tail -2 $O/pytest_gpu.log
 find $O -name "*.db" -delete; find $O -name "*kernel_trace.csv" -size +8M -delete
 du -sh $O
