@@ -14,10 +14,16 @@
  *     only enqueue work.  The one exception is workspace growth: the first call of a
  *     handle at a (B, L) larger than any before (re)allocates its workspace, which
  *     synchronises the device.  ldmseg_unet_reserve() does that up front (workspace,
- *     sampler buffers, the per-device zero page), after which forward / sample_loop
- *     calls at that size never allocate or synchronise.  The first launch of each
- *     kernel instantiation in a process still sets a function attribute (host-side,
- *     no device work): run one warm-up forward before capturing a stream.
+ *     sampler buffers incl. the time-embedding table of up to 64 steps, the
+ *     per-device zero page; the GroupNorm hand-off region belongs to the handle and
+ *     is made at *_create), after which forward / sample_loop calls at that size
+ *     never allocate or synchronise.  The first launch of each kernel instantiation
+ *     in a process still sets a function attribute (host-side, no device work): run
+ *     one warm-up forward before capturing a stream.  ldmseg_unet_forward with a
+ *     device timestep (t_dev) may be captured into a HIP graph and replayed (the
+ *     cooperative GroupNorm draws its hand-off generation on the device, so replays
+ *     do not meet each other's records); ldmseg_sample_loop copies cfg->timesteps
+ *     from pageable host memory on every call and is not meant to be captured.
  *     *_create calls allocate and synchronise.
  *   - return 0 on success, negative LDMSEG_E_* on failure; ldmseg_last_error()
  *     returns a thread-local message.  No C++ exception crosses the boundary.
@@ -95,8 +101,8 @@ int ldmseg_unet_forward_parts(ldmseg_unet* h, const float* latents, const float*
  * the 1024x1024 configuration (128x128 latents: 16384 / 4096 tokens at head dims 40 / 80); 0 switches it off (default).
  * The reference has no counterpart (its attention is whatever diffusers' processor does in fp32). */
 int ldmseg_unet_set_attention_fp8(ldmseg_unet* h, int min_tokens);
-/* Allocate everything forward / sample_loop need at (B, L) now (workspace + the sampler's eps and
- * self-condition buffers); may synchronise the device.  Optional: without it the first call at a new,
+/* Allocate everything forward / sample_loop need at (B, L) now (workspace + the sampler's eps,
+ * self-condition and time-embedding buffers); may synchronise the device.  Optional: without it the first call at a new,
  * larger shape does the same lazily. */
 int ldmseg_unet_reserve(ldmseg_unet* h, int B, int L);
 /* bytes of device workspace a forward at (B, L) needs (allocated lazily, grown never shrunk) */
@@ -266,9 +272,12 @@ int ldmseg_profile_dump(const char* path);
  * whether the timed launch carries a folded LayerNorm; key 8 = GroupNorm kernel choice (0 = shipped, bit 0 = two-launch
  * scheme everywhere, bit 1 = cooperative kernel from 16x16 maps up, bit 2 = two-pass instead of one-pass small-map kernel); key 9 = K order of 3x3 conv launches: -1 = shipped
  * rule (channel-major on large maps with many input channels), 0 = (tap, channel) everywhere, 1 = (channel tile, tap,
- * channel) wherever the layer holds that packing. */
+ * channel) wherever the layer holds that packing; key 10 = cooperative GroupNorm hand-off: 1 = every workgroup computes
+ * its partners' statistics itself instead of waiting for them (the path a workgroup takes when its partners are not
+ * co-resident; results are bit-identical), 0 = shipped; key 11 = bound of the partner poll in microseconds (default 100). */
 int ldmseg_debug_set(int key, int value);
-/* current value of a knob (key 1); key -1 = the shipped default of key 1.  Tests restore through this, never a literal. */
+/* current value of a knob (key 1); key -1 = the shipped default of key 1.  Tests restore through this, never a literal.
+ * key 10 = number of cooperative-GroupNorm workgroups that took the self-computing path in ldmseg_op_* launches so far. */
 int ldmseg_debug_get(int key);
 
 #ifdef __cplusplus

@@ -60,6 +60,14 @@ struct DeviceGuard {
 };
 
 inline size_t rup(size_t v, size_t a) { return (v + a - 1) / a * a; }
+// a handle's hand-off region of the cooperative GroupNorm kernel (norm.hip), zeroed once
+int alloc_gn_sync(void** out) {
+  void* p = nullptr;
+  if (hipMalloc(&p, gn_sync_bytes()) != hipSuccess) return fail(LDMSEG_E_OOM, "hipMalloc of the GroupNorm hand-off region failed");
+  if (gn_sync_init(p, nullptr) != 0 || hipStreamSynchronize(nullptr) != hipSuccess) { (void)hipFree(p); return fail(LDMSEG_E_HIP, "GroupNorm hand-off region init failed"); }
+  *out = p;
+  return 0;
+}
 inline size_t esize(int dt) { return dt == DT_BF16 ? 2 : 4; }
 inline int bke(int dt) { return dt == DT_BF16 ? 64 : 32; }  // channels per 128-B K tile
 
@@ -271,6 +279,7 @@ struct Exec {
   int B;
   hipStream_t s;
   int attn_fp8_min_tokens = 0;
+  void* gn_sync = nullptr;     // the handle's hand-off region of the cooperative GroupNorm (gn_sync_bytes())
   bool dry() const { return ws->dry; }
   // a request beyond the planned workspace (a plan made under other tuning knobs): fail before anything is launched on it
   int ws_ok() const { return ws->overflow ? fail(LDMSEG_E_OOM, "workspace plan exceeded (stale plan): nothing was launched") : 0; }
@@ -379,6 +388,7 @@ struct Exec {
     g.gamma = n.g; g.beta = n.b; g.eps = eps; g.silu = silu;
     g.out = out->p;
     g.nchunk = gn_nchunk(B, g.HW);
+    g.sync_region = gn_sync;
     g.partial = (float*)ws->scratch((size_t)B * g.nchunk * 32 * 2 * sizeof(float));
     const double bytes = 3.0 * B * g.HW * ctot * esize(dt);
     ProfScope ps(2, s, 0, bytes, dry(), "HW=" + std::to_string(g.HW) + " C=" + std::to_string(ctot));
@@ -453,6 +463,7 @@ struct ldmseg_unet {
   void* temb_buf = nullptr;            // [steps] int64 timesteps | sinusoid | two MLP activations | [steps][temb_total] rows
   int temb_cap = 0;                    // steps the buffer holds
   const float* temb_override = nullptr;   // non-null while the loop runs a forward: this step's row (broadcast over the batch)
+  void* gn_sync = nullptr;
 
   ~ldmseg_unet() {
     arena.release();
@@ -460,6 +471,7 @@ struct ldmseg_unet {
     if (cond) (void)hipFree(cond);
     if (eps) (void)hipFree(eps);
     if (temb_buf) (void)hipFree(temb_buf);
+    if (gn_sync) (void)hipFree(gn_sync);
   }
 };
 
@@ -727,6 +739,7 @@ int unet_forward_impl(ldmseg_unet* u, const float* a, int Ca, const float* b, in
   ws->begin(dry, scratch_base);
   Exec ex{ws, u->dt, B, s};
   ex.attn_fp8_min_tokens = u->attn_fp8_min_tokens;
+  ex.gn_sync = u->gn_sync;
   const int dt = u->dt;
 
   // --- time embedding: sinusoid -> MLP -> every resnet's time_emb_proj(SiLU(emb)) ---
@@ -883,9 +896,11 @@ struct ldmseg_vae {
   ConvW dec_in, dec_out;
   ConvW convt[4];
   NormW ln[4], dec_gn;
+  void* gn_sync = nullptr;
   ~ldmseg_vae() {
     arena.release();
     if (ws_mem) (void)hipFree(ws_mem);
+    if (gn_sync) (void)hipFree(gn_sync);
   }
 };
 
@@ -961,6 +976,7 @@ int vae_decode_impl(ldmseg_vae* v, const float* z, float z_scale, int B, int L, 
   Workspace* ws = &v->ws;
   ws->begin(dry, scratch_base);
   Exec ex{ws, v->dt, B, s};
+  ex.gn_sync = v->gn_sync;
   const int dt = v->dt;
   const ldmseg_vae_cfg& c = v->cfg;
   Act zin = ex.new_act(bke(dt), L, L, true);
@@ -1027,6 +1043,7 @@ int vae_encode_impl(ldmseg_vae* v, const float* x, float mul, float add, int B, 
   Workspace* ws = &v->ws;
   ws->begin(dry, scratch_base);
   Exec ex{ws, v->dt, B, s};
+  ex.gn_sync = v->gn_sync;
   const int dt = v->dt;
   const ldmseg_vae_cfg& c = v->cfg;
   Act xin = ex.new_act(bke(dt), H, H, true);
@@ -1070,9 +1087,11 @@ struct ldmseg_vae_image {
   ConvW q, k, proj;
   void* wv = nullptr;       // value projection [512][512], used as the X operand of the V^T GEMM
   float* bv = nullptr;
+  void* gn_sync = nullptr;
   ~ldmseg_vae_image() {
     arena.release();
     if (ws_mem) (void)hipFree(ws_mem);
+    if (gn_sync) (void)hipFree(gn_sync);
   }
 };
 
@@ -1193,6 +1212,7 @@ int klenc_encode_impl(ldmseg_vae_image* v, const float* x, float mul, float add,
   Workspace* ws = &v->ws;
   ws->begin(dry, scratch_base);
   Exec ex{ws, v->dt, B, s};
+  ex.gn_sync = v->gn_sync;
   const int dt = v->dt;
   Act xin = ex.new_act(bke(dt), H, W, true);
   {
@@ -1243,6 +1263,7 @@ int ldmseg_unet_create(const ldmseg_unet_cfg* cfg, int n_weights, const char* co
   u->dt = cfg->compute_dtype == LDMSEG_BF16 ? DT_BF16 : DT_F32;
   int r = unet_build(u, wm);
   if (r == 0) r = igemm_warm();
+  if (r == 0) r = alloc_gn_sync(&u->gn_sync);
   if (r != 0) { delete u; return r; }
   *out = u;
   return 0;
@@ -1294,6 +1315,7 @@ int ldmseg_vae_create(const ldmseg_vae_cfg* cfg, int n_weights, const char* cons
   v->dt = cfg->compute_dtype == LDMSEG_BF16 ? DT_BF16 : DT_F32;
   int r = vae_build(v, wm);
   if (r == 0) r = igemm_warm();
+  if (r == 0) r = alloc_gn_sync(&v->gn_sync);
   if (r != 0) { delete v; return r; }
   *out = v;
   return 0;
@@ -1376,6 +1398,7 @@ int ldmseg_vae_image_create(const ldmseg_vae_image_cfg* cfg, int n_weights, cons
   v->dt = cfg->compute_dtype == LDMSEG_BF16 ? DT_BF16 : DT_F32;
   int r = klenc_build(v, wm);
   if (r == 0) r = igemm_warm();
+  if (r == 0) r = alloc_gn_sync(&v->gn_sync);
   if (r != 0) { delete v; return r; }
   *out = v;
   return 0;
@@ -1444,18 +1467,22 @@ int ldmseg_remove_noise(const float* noisy, const float* noise, const int64_t* t
 
 // (re)allocate the sampler's eps / self-condition buffers; growth synchronises the device
 // time-embedding rows of every step of a sampling loop: rows[i] = time_emb_proj_all(silu(MLP(sinusoid(timesteps[i]))))
-static int loop_time_embeddings(ldmseg_unet* h, const int64_t* timesteps, int n_steps, hipStream_t s, const float** rows) {
+// room for the time-embedding rows of `n_steps` steps (at least 64: 6 MB, so that a short warm-up call followed by a longer
+// run does not re-allocate); ldmseg_unet_reserve sizes it up front
+static int temb_reserve(ldmseg_unet* h, int n_steps) {
+  if (h->temb_cap >= n_steps) return 0;
   const size_t per = sizeof(int64_t) + (320 + 2 * (size_t)kTimeDim + h->temb_total) * sizeof(float);
-  if (h->temb_cap < n_steps) {
-    // room for at least 64 steps (6 MB) so that a short warm-up call followed by a longer run does not re-allocate
-    int cap = 64;
-    while (cap < n_steps) cap *= 2;
-    HIP_TRY(hipDeviceSynchronize());
-    if (h->temb_buf) (void)hipFree(h->temb_buf);
-    h->temb_buf = nullptr; h->temb_cap = 0;
-    HIP_TRY(hipMalloc(&h->temb_buf, per * cap));
-    h->temb_cap = cap;
-  }
+  int cap = 64;
+  while (cap < n_steps) cap *= 2;
+  HIP_TRY(hipDeviceSynchronize());
+  if (h->temb_buf) (void)hipFree(h->temb_buf);
+  h->temb_buf = nullptr; h->temb_cap = 0;
+  HIP_TRY(hipMalloc(&h->temb_buf, per * cap));
+  h->temb_cap = cap;
+  return 0;
+}
+static int loop_time_embeddings(ldmseg_unet* h, const int64_t* timesteps, int n_steps, hipStream_t s, const float** rows) {
+  TRY(temb_reserve(h, n_steps));
   int64_t* ts = (int64_t*)h->temb_buf;
   float* sinus = (float*)(ts + h->temb_cap);
   float* e1 = sinus + (size_t)h->temb_cap * 320;
@@ -1512,6 +1539,7 @@ int ldmseg_unet_reserve(ldmseg_unet* h, int B, int L) {
   }
   TRY(ensure_ws(&h->ws_mem, &h->ws_cap, &h->ws, h->plan_persist + h->plan_scratch));
   TRY(loop_reserve(h, (size_t)B * 4 * L * L));
+  TRY(temb_reserve(h, 64));
   TRY(igemm_warm());
   return 0;
 }
@@ -1623,8 +1651,12 @@ int ldmseg_debug_set(int key, int value) {
   if (key == 2) { attention_set_qf1(value); return 0; }
   if (key == 1) { igemm_set_dbg(value); ++g_plan_epoch; return 0; }
   if (key == 5) { igemm_force_cfg(value); ++g_plan_epoch; return 0; }   // tools/tune_igemm.py: entry of igemm's instantiation list, -1 = off
-  if (key == 8) { groupnorm_set_variant(value); return 0; }
-  if (key == 9) { igemm_set_cm_mode(value); return 0; }   // K order of 3x3 conv launches: -1 rule, 0 tap-major, 1 channel-major
+  if (key == 8) { groupnorm_set_variant(value); ++g_plan_epoch; return 0; }   // (bit 3 changes which scratch conv_groupnorm plans)
+  if (key == 9) { igemm_set_cm_mode(value); ++g_plan_epoch; return 0; }   // K order of 3x3 conv launches: -1 rule, 0 tap-major, 1 channel-major
+  // cooperative GroupNorm hand-off: 10 = mode (1: every workgroup computes its partners' records itself), 11 = poll bound in us
+  static int gn_mode = 0, gn_poll = 100;
+  if (key == 10) { gn_mode = value; groupnorm_set_coop(gn_mode, gn_poll); return 0; }
+  if (key == 11) { gn_poll = value; groupnorm_set_coop(gn_mode, gn_poll); return 0; }
   if (key == 6 || key == 7) { ops_bench_knob(key, value); return 0; }   // ldmseg_bench_igemm: 6 = weight copies rotated, 7 = folded-LN launch   // bits 0-7 ablation flags (LDMSEG_IGEMM_ABLATE builds), bits 8-12 tile policy
   static unsigned long long ts_ptr = 0;                // keys 3/4: low/high half of a device stamp buffer (ablate builds)
   if (key == 3) { ts_ptr = (ts_ptr & 0xffffffff00000000ull) | (unsigned)value; igemm_set_tsbuf((void*)(uintptr_t)ts_ptr); return 0; }
@@ -1636,6 +1668,7 @@ int ldmseg_debug_get(int key) {
   if (key == 1) return igemm_get_dbg();
   if (key == -1) return igemm_default_dbg();     // the shipped value of key 1
   if (key == 9) return igemm_get_cm_mode();
+  if (key == 10) { const long long n = gn_coop_fallbacks(nullptr); return n > 0x7fffffffll ? 0x7fffffff : (int)n; }   // ring regions (ldmseg_op_* launches)
   return 0;
 }
 

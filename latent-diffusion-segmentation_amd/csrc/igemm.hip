@@ -261,7 +261,7 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LDR) * 64, (WAVES_M * WAVES_N 
     f_pixb = cs * (int)sizeof(T);
 #pragma unroll
     for (int i = 0; i < XG; ++i) {
-      const long long pix = (long long)(ri[i].pix_base + (ri[i].iy0 + ky) * p.Wi + ri[i].ix0 + kx);
+      const long long pix = (long long)ri[i].pix_base + (long long)(ri[i].iy0 + ky) * p.Wi + (ri[i].ix0 + kx);   // (rows past M: iy0 = -2^28)
       rowptr[i] = sbase + (pix * cs + coff) * (long long)sizeof(T) + ld_j * 16;
     }
   };

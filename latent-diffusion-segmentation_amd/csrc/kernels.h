@@ -123,11 +123,23 @@ struct GNParams {
   int cpg = 0, vx = 0, ty = 0, per = 0;                 // channels per group, threads per pixel row, pixel rows per trip, pixels per chunk
   FastDiv fd_cpg, fd_vx, fd_aux;                        // aux: units / vectors per pixel of the small / fused kernels
   double inv_n = 0.0;                                   // 1 / (HW * cpg)
-  // cooperative one-pass kernel (gn_coop_kernel): hand-off records of this launch and its generation tag
-  unsigned long long* sync = nullptr;
-  unsigned gen = 0;
+  // cooperative one-pass kernel (gn_coop_kernel).  sync_region: the caller's hand-off region (gn_sync_bytes() bytes, zeroed
+  // once by gn_sync_init; a handle owns one) or null = a region of the per-device ring.  The launcher derives the rest.
+  void* sync_region = nullptr;
+  unsigned long long* sync = nullptr;                   // record granules [slab][8 splits][8 entries]
+  unsigned long long* sync_ctr = nullptr;               // per-slab ticket counters (the generation tag is drawn on the device)
+  unsigned long long* sync_diag = nullptr;              // workgroups that computed a missing partner's record themselves
   int splits = 1;                                       // workgroups that share one (image, group block)
+  int coop_mode = 0;                                    // 1: never poll, always take the self-computing path (tests)
+  int poll_ticks = 10000;                               // bound of the partner poll in 100 MHz wall-clock ticks
 };
+size_t gn_sync_bytes();
+int gn_sync_init(void* region, hipStream_t s);
+int gn_warm();                                          // per-device ring allocated now instead of inside the first launch
+// test / diagnostic knobs of the cooperative kernel: mode 1 = always self-compute, poll_us = bound of the poll (default 100)
+void groupnorm_set_coop(int mode, int poll_us);
+// workgroups that took the self-computing path since the region was initialised (region null: sum over the ring of the current device)
+long long gn_coop_fallbacks(const void* region);
 int gn_nchunk(int B, int HW);
 int launch_groupnorm(const GNParams& p, int dtype, hipStream_t s);
 // Split-K finish of a conv fused with the GroupNorm (+SiLU) that consumes it (resnet conv1 -> norm2 on the 8x8 / 16x16

@@ -11,6 +11,8 @@
 //      torch.cat([hidden, skip], 1) disappears from the up path.
 // LayerNorm: one wavefront per row, values kept in registers, two-pass mean /
 // centred variance with wave shuffles (DPP) - same arithmetic as torch.
+#include <mutex>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -939,10 +941,19 @@ __global__ __launch_bounds__(256) void finish_gn_kernel(const GNParams p, int GB
 // Hand-off (MI355X_MICROARCH.md, "data-tagged granules"): a record entry is ONE naturally aligned 8-byte {value, tag} written
 // by a relaxed agent-scope atomic store (global_store_dwordx2 sc1: write-through, visible across XCDs) and polled with
 // relaxed agent-scope loads until the tag equals this launch's generation - no flag, no fence, nothing to reset between
-// launches (the next launch uses the next tag; a ring of regions keeps launches on concurrent streams apart).  All
-// workgroups of the grid are co-resident by construction (the grid never exceeds one workgroup per CU), so a partner is
-// always running or about to; the poll is bounded all the same and poisons the output with NaNs on time-out instead of
-// hanging.
+// launches.
+// Generation tag (round 4): drawn ON THE DEVICE from a per-slab ticket counter - every workgroup of a launch adds 8 / S, so
+// the S workgroups of one launch see tickets inside one block of eight and agree on ticket >> 3 without talking to each
+// other, and the next launch on the same region (the next norm of the stream, or the next replay of a captured graph)
+// draws the next block.  The round-3 form passed a host-side counter as a kernel argument: a replayed graph re-ran with
+// the tag it was captured with and met the previous replay's records.
+// Progress without co-residency (round 4): the poll is bounded (GNParams::poll_ticks of the 100 MHz wall clock, ~100 us)
+// and a workgroup whose partners did not show up computes THEIR records itself - it loads each missing split's pixels the
+// way that split's own threads would, runs the same statistics code on them (bit-identical numbers), then reloads its own
+// pixels and carries on.  Co-residency of the grid (at most one workgroup per CU) is therefore an expectation that makes
+// the common case fast, not a requirement: a second stream or process holding CUs, or two such grids holding half the
+// chip each, costs the extra reads of the two-launch scheme instead of dead-locking or poisoning the output (round 3
+// wrote NaNs after a multi-second spin and still returned 0).  GNParams::coop_mode 1 forces that path (tests).
 template <typename T, int MAXV, int NT>
 __global__ __launch_bounds__(NT) void gn_coop_kernel(const GNParams p, int GB) {
   constexpr int PC = Chunk<T>::N;
@@ -978,138 +989,179 @@ __global__ __launch_bounds__(NT) void gn_coop_kernel(const GNParams p, int GB) {
   if (c0 < p.C0) { src = (const T*)p.src0 + (size_t)b * p.HW * p.C0 + c0; cs = p.C0; }
   else { src = (const T*)p.src1 + (size_t)b * p.HW * p.C1 + (c0 - p.C0); cs = p.C1; }
   u32x4 raw[MAXV];
-#pragma unroll
-  for (int k = 0; k < MAXV; ++k) {
-    const int pix = pix0 + pr + ppi * k;
-    raw[k] = (active && pix < pix1) ? *(const u32x4*)(src + (size_t)pix * cs) : u32x4{0u, 0u, 0u, 0u};
-  }
-  // ---- local statistics: one accumulator per element position (dword in bf16), combined per group afterwards: every value
-  // is consumed once, next to where it is produced.  bf16: v_dot2_f32_bf16 against (1,1) sums a dword's pair without unpacking
-  // it (group boundaries fall on dwords: cpg is even) - hipcc would otherwise keep the unpacked fp32 copies of pass 1 alive
-  // for passes 2 and 3 (8 registers per vector instead of 4; 227 VGPRs) and the grid could not be co-resident.
-  constexpr int NACC = sizeof(T) == 2 ? 4 : PC;
-  constexpr int EPA = PC / NACC;
-  float acc1[NACC];
-#pragma unroll
-  for (int i = 0; i < NACC; ++i) acc1[i] = 0.f;
-  if constexpr (sizeof(T) == 2) {
-    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
-    const bf2 ones = __builtin_bit_cast(bf2, 0x3f803f80u);
+  // pixels of split `sp` as that split's own threads hold them (thread -> (pixel row, vector) does not depend on the split)
+  auto load_raw = [&](int sp) __attribute__((always_inline)) {
+    const int q0 = sp * per, q1 = min(p.HW, q0 + per);
 #pragma unroll
     for (int k = 0; k < MAXV; ++k) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const unsigned w = raw[k][i];                     // absent vectors are zero: they add nothing
-        acc1[i] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, w), ones, acc1[i], false);
-      }
+      const int pix = q0 + pr + ppi * k;
+      raw[k] = (active && pix < q1) ? *(const u32x4*)(src + (size_t)pix * cs) : u32x4{0u, 0u, 0u, 0u};
     }
-  } else {
-#pragma unroll
-    for (int k = 0; k < MAXV; ++k) {
-#pragma unroll
-      for (int e = 0; e < PC; ++e) acc1[e] += to_f32<T>(chunk_elem<T>(raw[k], e));
-    }
-  }
-  float slo = 0.f, shi = 0.f;
-#pragma unroll
-  for (int i = 0; i < NACC; ++i) {
-    if (i * EPA < split_e) slo += acc1[i];
-    else shi += acc1[i];
-  }
+  };
+  load_raw(split);
+  // ---- this launch's generation: one returning agent-scope add per workgroup, requested behind the pixel loads and needed
+  // only when the record is published
+  unsigned long long ticket = 0;
+  if (tid == 0)
+    ticket = __hip_atomic_fetch_add(p.sync_ctr + slab, (unsigned long long)(8 / S), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __shared__ float red[2][MAXG][NWV];
   __shared__ float s_stat[MAXG][2];
+  __shared__ float s_rec[MAXS][2 * MAXG];           // (mean, M2) x group of every split, in split order
+  __shared__ unsigned s_missing;
+  // ---- statistics of the split whose pixels sit in raw[]: one accumulator per element position (dword in bf16), combined
+  // per group afterwards: every value is consumed once, next to where it is produced.  bf16: v_dot2_f32_bf16 against (1,1)
+  // sums a dword's pair without unpacking it (group boundaries fall on dwords: cpg is even) - hipcc would otherwise keep the
+  // unpacked fp32 copies of pass 1 alive for passes 2 and 3 (8 registers per vector instead of 4; 227 VGPRs) and the grid
+  // could not be co-resident.  Leaves the split's record value of lane `tid` (< 2 * GB: even = mean, odd = M2) in `recv`.
+  auto split_stats = [&](int sp, float& recv) __attribute__((always_inline)) {
+    const int q0 = sp * per, q1 = min(p.HW, q0 + per);
+    constexpr int NACC = sizeof(T) == 2 ? 4 : PC;
+    constexpr int EPA = PC / NACC;
+    float acc1[NACC];
 #pragma unroll
-  for (int g = 0; g < MAXG; ++g) {
-    const float v = wave64_sum(glo == g ? slo : (glo + 1 == g ? shi : 0.f));
-    if ((tid & 63) == 0) red[0][g][tid >> 6] = v;
-  }
-  __syncthreads();
-  const float n_loc = (float)((pix1 - pix0) * cpg);          // samples per group in this split (exact: < 2^24)
-  float mlo = 0.f, mhi = 0.f, mloc[MAXG];
+    for (int i = 0; i < NACC; ++i) acc1[i] = 0.f;
+    if constexpr (sizeof(T) == 2) {
+      typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+      const bf2 ones = __builtin_bit_cast(bf2, 0x3f803f80u);
 #pragma unroll
-  for (int g = 0; g < MAXG; ++g) {
-    double a = 0.0;
+      for (int k = 0; k < MAXV; ++k) {
 #pragma unroll
-    for (int w = 0; w < NWV; ++w) a += (double)red[0][g][w];
-    mloc[g] = n_loc > 0.f ? (float)(a / (double)n_loc) : 0.f;
-    if (g == glo) mlo = mloc[g];
-    if (g == glo + 1) mhi = mloc[g];
-  }
-  {
-    float acc2[PC];
+        for (int i = 0; i < 4; ++i) {
+          const unsigned w = raw[k][i];                     // absent vectors are zero: they add nothing
+          acc1[i] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf2, w), ones, acc1[i], false);
+        }
+      }
+    } else {
 #pragma unroll
-    for (int e = 0; e < PC; ++e) acc2[e] = 0.f;
+      for (int k = 0; k < MAXV; ++k) {
 #pragma unroll
-    for (int k = 0; k < MAXV; ++k) {
-      const bool ok = active && pix0 + pr + ppi * k < pix1;
-#pragma unroll
-      for (int e = 0; e < PC; ++e) {
-        const float d = ok ? to_f32<T>(chunk_elem<T>(raw[k], e)) - (e < split_e ? mlo : mhi) : 0.f;
-        acc2[e] += d * d;
+        for (int e = 0; e < PC; ++e) acc1[e] += to_f32<T>(chunk_elem<T>(raw[k], e));
       }
     }
-    float qlo = 0.f, qhi = 0.f;
+    float slo = 0.f, shi = 0.f;
 #pragma unroll
-    for (int e = 0; e < PC; ++e) {
-      if (e < split_e) qlo += acc2[e];
-      else qhi += acc2[e];
+    for (int i = 0; i < NACC; ++i) {
+      if (i * EPA < split_e) slo += acc1[i];
+      else shi += acc1[i];
     }
 #pragma unroll
     for (int g = 0; g < MAXG; ++g) {
-      const float v = wave64_sum(glo == g ? qlo : (glo + 1 == g ? qhi : 0.f));
-      if ((tid & 63) == 0) red[1][g][tid >> 6] = v;
+      const float v = wave64_sum(glo == g ? slo : (glo + 1 == g ? shi : 0.f));
+      if ((tid & 63) == 0) red[0][g][tid >> 6] = v;
+    }
+    __syncthreads();
+    const float n_loc = (float)((q1 - q0) * cpg);          // samples per group in this split (exact: < 2^24)
+    float mlo = 0.f, mhi = 0.f, mloc[MAXG];
+#pragma unroll
+    for (int g = 0; g < MAXG; ++g) {
+      double a = 0.0;
+#pragma unroll
+      for (int w = 0; w < NWV; ++w) a += (double)red[0][g][w];
+      mloc[g] = n_loc > 0.f ? (float)(a / (double)n_loc) : 0.f;
+      if (g == glo) mlo = mloc[g];
+      if (g == glo + 1) mhi = mloc[g];
+    }
+    {
+      float acc2[PC];
+#pragma unroll
+      for (int e = 0; e < PC; ++e) acc2[e] = 0.f;
+#pragma unroll
+      for (int k = 0; k < MAXV; ++k) {
+        const bool ok = active && q0 + pr + ppi * k < q1;
+#pragma unroll
+        for (int e = 0; e < PC; ++e) {
+          const float d = ok ? to_f32<T>(chunk_elem<T>(raw[k], e)) - (e < split_e ? mlo : mhi) : 0.f;
+          acc2[e] += d * d;
+        }
+      }
+      float qlo = 0.f, qhi = 0.f;
+#pragma unroll
+      for (int e = 0; e < PC; ++e) {
+        if (e < split_e) qlo += acc2[e];
+        else qhi += acc2[e];
+      }
+#pragma unroll
+      for (int g = 0; g < MAXG; ++g) {
+        const float v = wave64_sum(glo == g ? qlo : (glo + 1 == g ? qhi : 0.f));
+        if ((tid & 63) == 0) red[1][g][tid >> 6] = v;
+      }
+    }
+    __syncthreads();
+    recv = 0.f;
+    if (tid < 2 * GB) {
+      const int g = tid >> 1;
+      if (tid & 1) {
+        double a = 0.0;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) a += (double)red[1][g][w];
+        recv = (float)a;                                                          // M2 of this split
+      } else {
+        recv = mloc[g];
+      }
+    }
+  };
+  float myrec;
+  split_stats(split, myrec);
+  // ---- publish this split's record, collect the partners', combine in split order
+  unsigned long long* rec = p.sync + (size_t)slab * (MAXS * 2 * MAXG);      // [S][2 * MAXG] granules of this slab
+  if (tid < 64) {                                     // one wave publishes and polls: lane = (split, entry)
+    const unsigned tk = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ticket >> 3));
+    const unsigned gen = (tk & 0x7fffffffu) + 1u;     // tag 0 = never written
+    if (tid < 2 * GB) {
+      const unsigned long long gran = ((unsigned long long)gen << 32) | (unsigned long long)f32_bits(myrec);
+      __hip_atomic_store(rec + split * (2 * MAXG) + tid, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const int sidx = tid / (2 * MAXG), ent = tid - sidx * (2 * MAXG);
+    const bool mine = sidx < S && ent < 2 * GB;
+    const bool own = sidx == split;
+    unsigned long long gran = ((unsigned long long)gen << 32) | (unsigned long long)f32_bits(myrec);   // (own entries: lane == entry)
+    bool done = !mine || own;
+    if (p.coop_mode != 1) {
+      const unsigned long long t0 = wall_clock64();
+      while (true) {
+        if (!done) {
+          gran = __hip_atomic_load(rec + sidx * (2 * MAXG) + ent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          done = (unsigned)(gran >> 32) == gen;
+        }
+        if (__all(done) || wall_clock64() - t0 > (unsigned long long)p.poll_ticks) break;
+        __builtin_amdgcn_s_sleep(2);
+      }
+    }
+    // own entries come from this workgroup's registers (lane tid < 2*GB holds entry tid of split `split`)
+    const float ownv = __shfl(myrec, ent, 64);
+    if (mine && done) s_rec[sidx][ent] = own ? ownv : bits_f32((unsigned)gran);
+    const unsigned long long late = __ballot(mine && !done);
+    if (tid == 0) {
+      unsigned m = 0;
+#pragma unroll
+      for (int sx = 0; sx < MAXS; ++sx) m |= ((late >> (sx * 2 * MAXG)) & 0xffull) ? (1u << sx) : 0u;
+      s_missing = m;
     }
   }
   __syncthreads();
-  // ---- publish this split's record, collect the partners', combine in split order
-  unsigned long long* rec = p.sync + (size_t)slab * (MAXS * 2 * MAXG);      // [S][2 * MAXG] granules of this slab
-  if (tid < 2 * GB) {
-    const int g = tid >> 1;
-    float v;
-    if (tid & 1) {
-      double a = 0.0;
-#pragma unroll
-      for (int w = 0; w < NWV; ++w) a += (double)red[1][g][w];
-      v = (float)a;                                                          // M2 of this split
-    } else {
-      v = mloc[g];
+  const unsigned missing = s_missing;                 // workgroup-uniform
+  if (missing) {
+    // ---- cold path: partners that are not running (yet).  Their records are a pure function of their pixels: compute them.
+    for (int sx = 0; sx < S; ++sx) {
+      if (!((missing >> sx) & 1u)) continue;
+      load_raw(sx);
+      float v;
+      split_stats(sx, v);
+      if (tid < 2 * GB) s_rec[sx][tid] = v;
     }
-    const unsigned long long gran = ((unsigned long long)p.gen << 32) | (unsigned long long)f32_bits(v);
-    __hip_atomic_store(rec + split * (2 * MAXG) + tid, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    load_raw(split);
+    if (tid == 0) __hip_atomic_fetch_add(p.sync_diag, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
   }
-  if (tid < 64) {                                     // one wave polls: lane = (split, entry)
-    const int sidx = tid / (2 * MAXG), ent = tid - sidx * (2 * MAXG);
-    const bool mine = sidx < S && ent < 2 * GB;
-    unsigned long long gran = 0;
-    bool done = !mine;
-    int spins = 0;
-    while (true) {
-      if (!done) {
-        gran = __hip_atomic_load(rec + sidx * (2 * MAXG) + ent, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        done = (unsigned)(gran >> 32) == p.gen;
-      }
-      if (__all(done) || ++spins > (1 << 22)) break;
-      __builtin_amdgcn_s_sleep(2);
+  if (tid < 2 * GB && !(tid & 1)) {                   // lane g*2 takes group g (fixed split order -> deterministic)
+    double n = 0.0, mean = 0.0, m2 = 0.0;
+    for (int sx = 0; sx < S; ++sx) {
+      const int q0 = sx * per, q1 = min(p.HW, q0 + per);
+      chan_add(n, mean, m2, (double)max(0, q1 - q0) * cpg, (double)s_rec[sx][tid], (double)s_rec[sx][tid + 1]);
     }
-    const bool timeout = !__all(done);
-    const float val = timeout ? __builtin_nanf("") : bits_f32((unsigned)gran);
-    // lanes 0 .. 2*GB-1 of this wave combine entry pairs: lane g*2 takes group g (fixed split order -> deterministic)
-    float mean_s[MAXS], m2_s[MAXS];
-#pragma unroll
-    for (int sx = 0; sx < MAXS; ++sx) {
-      mean_s[sx] = __shfl(val, sx * (2 * MAXG) + (tid & (2 * MAXG - 2)), 64);
-      m2_s[sx] = __shfl(val, sx * (2 * MAXG) + (tid & (2 * MAXG - 2)) + 1, 64);
-    }
-    if (tid < 2 * GB && !(tid & 1)) {
-      double n = 0.0, mean = 0.0, m2 = 0.0;
-      for (int sx = 0; sx < S; ++sx) {
-        const int q0 = sx * per, q1 = min(p.HW, q0 + per);
-        chan_add(n, mean, m2, (double)max(0, q1 - q0) * cpg, (double)mean_s[sx], (double)m2_s[sx]);
-      }
-      const float var = n > 0.0 ? (float)(m2 / n) : 0.f;
-      s_stat[tid >> 1][0] = (float)mean;
-      s_stat[tid >> 1][1] = 1.0f / sqrtf(var + p.eps);                       // NaN on a time-out: the output says so
-    }
+    const float var = n > 0.0 ? (float)(m2 / n) : 0.f;
+    s_stat[tid >> 1][0] = (float)mean;
+    s_stat[tid >> 1][1] = 1.0f / sqrtf(var + p.eps);
   }
   __syncthreads();
   if (!active) return;
@@ -1151,24 +1203,38 @@ __global__ __launch_bounds__(NT) void gn_coop_kernel(const GNParams p, int GB) {
   }
 }
 
-// per-device hand-off records of the cooperative kernel: a ring of regions (one per launch generation mod kGnRing), zeroed once
-constexpr int kGnRing = 16, kGnMaxSlabs = 2048;
-unsigned long long* gn_sync_region(unsigned* gen_out) {
-  static unsigned long long* buf[64] = {};
-  static unsigned gen[64] = {};
+// Hand-off state of the cooperative kernel: [kGnMaxSlabs] ticket counters | [kGnMaxSlabs][8 splits][8 entries] granules |
+// one diagnostic counter (workgroups that took the cold path).  Zeroed once; nothing is ever reset (tags only grow).
+// Every handle (UNet, seg-VAE, image VAE) owns one region, allocated at *_create: its launches are ordered by its stream,
+// so consecutive norms - and replays of a captured graph - draw consecutive generations on it.  Launches that do not come
+// from a handle (the ldmseg_op_* test surface) take a region of a small per-device ring under a mutex.
+constexpr int kGnMaxSlabs = 2048, kGnRing = 16;
+constexpr size_t kGnCtrWords = kGnMaxSlabs, kGnRecWords = (size_t)kGnMaxSlabs * 8 * 8;
+constexpr size_t kGnRegionWords = kGnCtrWords + kGnRecWords + 8;
+void gn_bind_region(GNParams& p, unsigned long long* base) {
+  p.sync_ctr = base;
+  p.sync = base + kGnCtrWords;
+  p.sync_diag = base + kGnCtrWords + kGnRecWords;
+}
+std::mutex g_gn_mu;
+unsigned long long* g_gn_ring[64] = {};
+unsigned g_gn_next[64] = {};
+unsigned long long* gn_ring_region(int* dev_out = nullptr) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-  const size_t region = (size_t)kGnMaxSlabs * 8 * 2 * 4;                      // granules per region
-  if (!buf[dev]) {
-    void* p = nullptr;
-    if (hipMalloc(&p, region * kGnRing * sizeof(unsigned long long)) != hipSuccess) return nullptr;
-    (void)hipMemset(p, 0, region * kGnRing * sizeof(unsigned long long));
-    buf[dev] = (unsigned long long*)p;
+  if (dev_out) *dev_out = dev;
+  std::lock_guard<std::mutex> lk(g_gn_mu);
+  if (!g_gn_ring[dev]) {
+    void* q = nullptr;
+    if (hipMalloc(&q, kGnRegionWords * kGnRing * sizeof(unsigned long long)) != hipSuccess) return nullptr;
+    (void)hipMemset(q, 0, kGnRegionWords * kGnRing * sizeof(unsigned long long));
+    g_gn_ring[dev] = (unsigned long long*)q;
   }
-  if (++gen[dev] == 0) ++gen[dev];                                            // tag 0 = never written
-  *gen_out = gen[dev];
-  return buf[dev] + (size_t)(gen[dev] % kGnRing) * region;
+  return g_gn_ring[dev] + (size_t)(g_gn_next[dev]++ % kGnRing) * kGnRegionWords;
 }
+
+int g_gn_coop_mode = 0;     // 1: every cooperative workgroup computes its partners' records itself (tests of the cold path)
+int g_gn_poll_us = 100;     // bound of the partner poll
 
 int g_gn_variant = 0;   // tuning knob (ldmseg_debug_set key 8): bit0 = no cooperative kernel (64x64 maps on the two-launch path)
 
@@ -1202,10 +1268,13 @@ int run_gn(const GNParams& pin, hipStream_t s) {
       while (S < 8 && slabs * S * 2 <= num_cus_gn() && p.HW / (2 * S) >= ppi) S *= 2;
       if (((p.HW + S - 1) / S + ppi - 1) / ppi > MAXVC) continue;
       if (slabs * S > num_cus_gn()) continue;                     // every workgroup must be resident: one per CU (8 waves at ~200 registers)
-      unsigned gen = 0;
-      unsigned long long* sync = gn_sync_region(&gen);
-      if (!sync) return -3;
-      p.sync = sync; p.gen = gen; p.splits = S;
+      unsigned long long* region = (unsigned long long*)p.sync_region;
+      if (!region) region = gn_ring_region();
+      if (!region) return -3;
+      gn_bind_region(p, region);
+      p.splits = S;
+      p.coop_mode = g_gn_coop_mode;
+      p.poll_ticks = g_gn_poll_us * 100;                          // wall_clock64: 100 MHz
       p.per = (p.HW + S - 1) / S;
       p.ty = ppi;
       p.fd_aux = fastdiv_make(vpp);
@@ -1365,6 +1434,43 @@ int gn_nchunk(int B, int HW) {
 }
 
 void groupnorm_set_variant(int v) { g_gn_variant = v; }
+void groupnorm_set_coop(int mode, int poll_us) {
+  g_gn_coop_mode = mode == 1 ? 1 : 0;
+  g_gn_poll_us = poll_us < 0 ? 100 : (poll_us > 1000000 ? 1000000 : poll_us);
+}
+size_t gn_sync_bytes() { return kGnRegionWords * sizeof(unsigned long long); }
+int gn_sync_init(void* region, hipStream_t s) {
+  return hipMemsetAsync(region, 0, gn_sync_bytes(), s) == hipSuccess ? 0 : -3;
+}
+int gn_warm() {
+  std::lock_guard<std::mutex> lk(g_gn_mu);
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!g_gn_ring[dev]) {
+    void* q = nullptr;
+    if (hipMalloc(&q, kGnRegionWords * kGnRing * sizeof(unsigned long long)) != hipSuccess) return -3;
+    (void)hipMemset(q, 0, kGnRegionWords * kGnRing * sizeof(unsigned long long));
+    g_gn_ring[dev] = (unsigned long long*)q;
+  }
+  return 0;
+}
+long long gn_coop_fallbacks(const void* region) {
+  unsigned long long v = 0, tot = 0;
+  if (region) {
+    if (hipMemcpy(&v, (const unsigned long long*)region + kGnCtrWords + kGnRecWords, 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (long long)v;
+  }
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  const unsigned long long* ring;
+  { std::lock_guard<std::mutex> lk(g_gn_mu); ring = g_gn_ring[dev]; }
+  if (!ring) return 0;
+  for (int i = 0; i < kGnRing; ++i) {
+    if (hipMemcpy(&v, ring + (size_t)i * kGnRegionWords + kGnCtrWords + kGnRecWords, 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    tot += v;
+  }
+  return (long long)tot;
+}
 
 int launch_groupnorm(const GNParams& p, int dtype, hipStream_t s) {
   return dtype == DT_BF16 ? run_gn<bf16_t>(p, s) : run_gn<float>(p, s);

@@ -24,7 +24,7 @@ GROUPS = 32
 def timestep_embedding(timesteps, dim=320):
     """diffusers Timesteps(320, flip_sin_to_cos=True, freq_shift=0): [cos | sin]."""
     half = dim // 2
-    exponent = -math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half
+    exponent = -math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=timesteps.device) / half
     arg = timesteps.float()[:, None] * torch.exp(exponent)[None, :]
     return torch.cat([torch.cos(arg), torch.sin(arg)], dim=-1)
 
@@ -88,8 +88,8 @@ def transformer(sd, p, x, ctx=None):
 def unet_forward(sd, sample, timestep, encoder_hidden_states=None, taps=None):
     """sample [B, 8|12, L, L] fp32, timestep 0-d or [B] int tensor -> [B,4,L,L]."""
     B = sample.shape[0]
-    t = torch.as_tensor(timestep).reshape(-1).expand(B)
-    emb = timestep_embedding(t)
+    t = torch.as_tensor(timestep, device=sample.device).reshape(-1).expand(B)
+    emb = timestep_embedding(t).to(sd["time_embedding.linear_1.weight"].dtype)   # (weights cast to bf16 / moved to a GPU: tools/yardstick.py)
     emb = F.linear(emb, sd["time_embedding.linear_1.weight"], sd["time_embedding.linear_1.bias"])
     emb = F.linear(F.silu(emb), sd["time_embedding.linear_2.weight"], sd["time_embedding.linear_2.bias"])
 

@@ -40,6 +40,12 @@ def test_two_ranks_over_gloo_share_the_device_and_say_so():
     # the decomposition a multi-GPU run is read by: every rank's own step time and the one collective on its own
     assert len(out["per_rank_ms_per_step"]) == 2 and max(out["per_rank_ms_per_step"]) == pytest.approx(out["ms_per_step"], rel=1e-6)
     assert out["allgather_latents"]["bytes_per_rank"] == 8 * 4 * 64 * 64 * 4 and out["allgather_latents"]["us"] > 0
+    # two PROCESSES share the device here: the cooperative GroupNorm grids of one cannot count on co-residency.  Every rank's
+    # latents of every timed region must be finite (all-reduced MIN over ranks in bench.py) - VERDICT r03 weak 9
+    assert out["finite"] is True
+    assert out["timed_regions"]["n"] == 3 and len(out["timed_regions"]["ms_per_step"]) == 3
+    assert out["timed_regions"]["ms_per_step"][0] == pytest.approx(out["ms_per_step"], rel=1e-3)
+    assert out["timed_regions"]["min_ms_per_step"] <= out["timed_regions"]["median_ms_per_step"]
 
 
 def test_two_ranks_over_rccl_when_two_devices_are_visible():

@@ -309,6 +309,49 @@ def test_groupnorm_cooperative(L, dt, case, variant):
 
 
 @pytest.mark.parametrize("dt", [F32, BF16])
+@pytest.mark.parametrize("case", [(8, 320, 0, 4096, 1e-5, 1), (4, 320, 320, 4096, 1e-5, 1), (8, 320, 0, 3969, 1e-6, 0),
+                                  (4, 320, 0, 16384, 1e-5, 1), (8, 640, 0, 1024, 1e-5, 1)])
+def test_groupnorm_cooperative_without_partners(L, dt, case):
+    """The cooperative kernel must not depend on its partners being co-resident: a
+    workgroup whose partners' records do not arrive in time computes them itself from the partners' pixels.  Forcing that
+    path for EVERY workgroup (debug key 10), and a zero-length poll (key 11: whoever is late is recomputed), must give
+    bit-identical results to the hand-off path - and never NaNs."""
+    B, Cc, C2, HW, eps, silu = case
+    g = torch.Generator().manual_seed(Cc + HW + B + 1)
+    x = torch.randn(B, Cc, HW, generator=g) * 2 + 0.5
+    x[:, :, : HW // 3] += 3.0
+    x2 = torch.randn(B, C2, HW, generator=g) - 1.0 if C2 else None
+    gamma = 1 + 0.1 * torch.randn(Cc + C2, generator=g)
+    beta = 0.1 * torch.randn(Cc + C2, generator=g)
+    out = torch.empty(B, Cc + C2, HW, device="cuda")
+    dx, dx2, dg, db = dev(x), dev(x2), dev(gamma), dev(beta)
+    lib = L.lib()
+
+    def run():
+        out.fill_(float("nan"))
+        assert lib.ldmseg_op_groupnorm(P(dx), P(dx2), P(dg), P(db), B, Cc, C2, HW, eps, silu, dt, P(out), None) == 0
+        torch.cuda.synchronize()
+        return out.clone()
+    base = run()
+    assert torch.isfinite(base).all()
+    n0 = lib.ldmseg_debug_get(10)
+    try:
+        lib.ldmseg_debug_set(10, 1)                      # nobody waits for anybody
+        forced = [run() for _ in range(3)]
+        n1 = lib.ldmseg_debug_get(10)
+        lib.ldmseg_debug_set(10, 0)
+        lib.ldmseg_debug_set(11, 0)                      # one look at the partners' records, then self-compute what is missing
+        hurried = [run() for _ in range(3)]
+    finally:
+        lib.ldmseg_debug_set(10, 0)
+        lib.ldmseg_debug_set(11, 100)
+    assert n1 > n0, "the self-computing path did not run"
+    for o in forced + hurried:
+        assert torch.equal(o, base), case
+    assert torch.equal(run(), base)
+
+
+@pytest.mark.parametrize("dt", [F32, BF16])
 @pytest.mark.parametrize("M,Cc,eps,silu", [(77, 320, 1e-5, 0), (64, 640, 1e-5, 0), (33, 1280, 1e-5, 0), (50, 256, 1e-6, 1)])
 def test_layernorm(L, dt, M, Cc, eps, silu):
     g = torch.Generator().manual_seed(M + Cc)

@@ -289,9 +289,87 @@ def test_bf16_trajectory_parity(unets, unet_sd, vae_sd, sched_kw):
     agree_modes = float((ids["bf16"] == ids["fp32"]).float().mean())
     print(f"trajectory parity: relL2 fp32-vs-oracle {e_f32:.3e}, bf16-vs-oracle {e_bf16:.3e}, bf16-vs-fp32 {e_bf16_vs_f32:.3e}; "
           f"argmax agreement fp32 {agree_f32:.4f}, bf16 {agree_bf16:.4f}, bf16-vs-fp32 {agree_modes:.4f}")
-    assert e_f32 < 2e-3 and agree_f32 > 0.995
-    assert e_bf16 < 8e-2 and e_bf16_vs_f32 < 8e-2
-    assert agree_bf16 > 0.93 and agree_modes > 0.93
+    # measured on MI355X (round 3): fp32 6.6e-7 / 100 %, bf16 2.4e-3 / 98.8 %.  Bounds = 2x the measured deviation
+    # (the old 8e-2 / 0.93 would have passed a real regression of the bf16 path)
+    assert e_f32 < 2e-5 and agree_f32 > 0.999
+    assert e_bf16 < 5e-3 and e_bf16_vs_f32 < 5e-3
+    assert agree_bf16 > 0.975 and agree_modes > 0.975
+
+
+def test_bf16_trajectory_parity_l64(unets, unet_sd, sched_kw):
+    """The same question at the headline latent size (L = 64, the configs[1] geometry): a 10-step DDIM trajectory of one
+    image from the same noise, fp32 and bf16 HIP paths against the oracle's (10 CPU forwards at L = 64, ~1 min)."""
+    from ldmseg_amd.models import GeneralVAESeg  # noqa: F401
+    from ldmseg_amd.schedulers import DDIMNoiseScheduler
+    from ldmseg_amd.trainers import TrainerDiffusion
+    torch.set_num_threads(32)
+    rgb = 0.18215 * torch.randn(1, 4, 64, 64, generator=torch.Generator().manual_seed(1234))
+    noise = torch.randn(1, 4, 64, 64, generator=torch.Generator().manual_seed(42))
+    outs = {}
+    for mode in ("fp32", "bf16"):
+        tr = TrainerDiffusion(None, unets[mode], DDIMNoiseScheduler(**sched_kw))
+        outs[mode] = tr.sample([""], num_inference_steps=10, seed=42, rgb_latents=rgb.to(DEV), latents=noise.clone())
+    so = o_ddim.OracleDDIM(**sched_kw)
+    so.set_timesteps_inference(10)
+    with torch.no_grad():
+        ref = o_sample.sample(lambda inp, t: o_unet.unet_forward(unet_sd, inp, t), so, rgb, seed=42, noise=noise.clone())
+    rl2 = lambda a, b: float((a.double().cpu() - b.double().cpu()).norm() / b.double().cpu().norm())
+    e_f32, e_bf16 = rl2(outs["fp32"], ref), rl2(outs["bf16"], ref)
+    print(f"L=64 10-step trajectory: relL2 fp32-vs-oracle {e_f32:.3e}, bf16-vs-oracle {e_bf16:.3e}")
+    assert e_f32 < 2e-5
+    assert e_bf16 < 1e-2
+
+
+def test_two_handles_on_two_streams_concurrently(unet_sd):
+    """Two UNet handles running forwards at the same time on two streams share the CUs, so the cooperative GroupNorm grids
+    of one cannot count on being resident together.  Every concurrent forward must equal the forward
+    the same handle computes alone, bit for bit, 20 times in a row."""
+    from ldmseg_amd.models import UNet
+    ua = UNet(unet_sd, in_channels=12, device=DEV, compute_dtype="bf16")
+    ub = UNet(unet_sd, in_channels=12, device=DEV, compute_dtype="bf16")
+    g = torch.Generator().manual_seed(77)
+    xa = torch.randn(4, 12, 64, 64, generator=g).to(DEV)
+    xb = torch.randn(2, 12, 64, 64, generator=g).to(DEV)
+    t = torch.tensor(481, device=DEV)
+    ya, yb = ua(xa, t).sample.clone(), ub(xb, t).sample.clone()
+    torch.cuda.synchronize()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    for it in range(20):
+        with torch.cuda.stream(sa):
+            oa = [ua(xa, t).sample for _ in range(2)][-1]
+        with torch.cuda.stream(sb):
+            ob = [ub(xb, t).sample for _ in range(3)][-1]
+        torch.cuda.synchronize()
+        assert torch.isfinite(oa).all() and torch.isfinite(ob).all(), it
+        assert torch.equal(oa, ya) and torch.equal(ob, yb), it
+
+
+def test_forward_graph_capture_and_replay(unets):
+    """ldmseg_unet_forward with a device timestep captured into a HIP graph (after one warm-up) and replayed: the
+    cooperative GroupNorm draws its hand-off generation on the device, so a replay does not mistake the previous replay's
+    records for its own.  Replays on new inputs must equal eager forwards bit for bit."""
+    u = unets["bf16"]
+    g = torch.Generator().manual_seed(5)
+    xs = [torch.randn(2, 12, 64, 64, generator=g).to(DEV) for _ in range(3)]
+    t = torch.tensor([333], device=DEV, dtype=torch.int64)
+    eager = [u(x, t).sample.clone() for x in xs]
+    torch.cuda.synchronize()
+    x_static = xs[0].clone()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        u(x_static, t)                                   # warm-up on the capture stream
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=s):
+        y_static = u(x_static, t).sample
+    for rep in range(2):
+        for x, ref in zip(xs, eager):
+            x_static.copy_(x)
+            graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(y_static, ref), rep
 
 
 def test_unet_conv_k_order_modes_agree(unets):
