@@ -345,7 +345,8 @@ def test_groupnorm_cooperative_without_partners(L, dt, case):
     finally:
         lib.ldmseg_debug_set(10, 0)
         lib.ldmseg_debug_set(11, 100)
-    assert n1 > n0, "the self-computing path did not run"
+    # (fp32 at 128 x 128: 64 slabs x 8 splits exceed one workgroup per CU - that shape stays on the two-launch scheme)
+    assert n1 > n0 or (dt == F32 and HW == 16384), "the self-computing path did not run"
     for o in forced + hurried:
         assert torch.equal(o, base), case
     assert torch.equal(run(), base)
