@@ -68,6 +68,13 @@ int ldmseg_op_conv_groupnorm(const float* x, const float* w, const float* bias, 
  * the un-normalised x with gamma folded into the weights and rstd*(acc - mean*c1) + c2 in the epilogue. */
 int ldmseg_op_ln_linear(const float* x, const float* gamma, const float* beta, const float* w, const float* bias, int M, int K,
                         int N, float eps, int geglu, int dtype, float* out, void* stream);
+/* The tail of a transformer block on [M, C] token rows (diffusers BasicTransformerBlock.ff + Transformer2DModel.proj_out,
+ * /root/reference/ldmseg/models/unet.py:401-425):  h2 = h + ff.net.2(GEGLU(ff.net.0.proj(LayerNorm(h))));  out = proj_out(h2) + x.
+ * mode 0 = the unfused launches, 1 = row-local fused feed-forward (tfuse.hip) + proj_out GEMM, 3 = all in the fused kernel
+ * (modes 1 / 3: bf16, C = 320).  time_iters > 0: *us_per_call = average microseconds of the whole tail. */
+int ldmseg_op_transformer_ff(const float* h, const float* x, const float* gamma, const float* beta, const float* w1, const float* b1,
+                             const float* w2, const float* b2, const float* wp, const float* bp, int M, int C, float eps, int dtype,
+                             int mode, float* out, int time_iters, float* us_per_call, void* stream);
 /* Kernel timing for tuning (tools/kbench.py): the same launches repeated `iters` times back to back on `stream` between
  * two HIP events; *us_per_launch = average microseconds (igemm: including the split-K finish kernel if the plan has one). */
 int ldmseg_bench_igemm(const float* x, const float* x2, const float* w, const float* bias, const float* resid,

@@ -430,6 +430,7 @@ struct TransformerW {
   int C = 0;
   NormW norm, ln1, ln3;
   ConvW proj_in, qkv, attn_out, ff1, ff2, proj_out;
+  void* mlp_stream = nullptr;   // 320-channel level, bf16: the feed-forward's weights as one consumption-ordered stream (tfuse.hip)
 };
 
 }  // namespace
@@ -563,6 +564,10 @@ int build_transformer(Builder& b, const std::string& p, int C, TransformerW* t) 
   }
   TRY(b.conv(tb + "ff.net.2", C, 4 * C, 1, 4 * C, &t->ff2));
   TRY(b.conv(p + "proj_out", C, C, 1, C, &t->proj_out));
+  if (const size_t sb = (dt == DT_BF16 && t->ff1.N == 8 * C && t->ff2.N == C && t->proj_out.N == C) ? mlp_fused_stream_bytes(C) : 0) {
+    TRY(b.arena->alloc(&t->mlp_stream, sb));
+    TRY(launch_pack_mlp_stream(t->ff1.w, t->ff2.w, t->proj_out.w, t->mlp_stream, C, b.s));
+  }
   return 0;
 }
 
@@ -705,6 +710,26 @@ int run_transformer(Exec& ex, const TransformerW& t, const Act& x, Act* out) {
     p.M = M; p.N = t.attn_out.N; p.n_valid = C; p.W = t.attn_out.w; p.bias = t.attn_out.bias;
     p.resid = h.p; p.ldr = C; p.out = h.p; p.ldo = C;
     TRY(ex.igemm(p));
+  }
+  if (t.mlp_stream && mlp_fused_ok(C, ex.dt)) {
+    // 320-channel level: norm3 -> GEGLU -> ff.net.2 (+h) [-> proj_out (+x)] in one row-local launch (tfuse.hip); the [M, 4C]
+    // hidden tensor and the statistics pass never exist
+    const bool proj = mlp_fused_proj();
+    if (proj) *out = ex.new_act(C, x.H, x.W, true);
+    {
+      const double flops = 2.0 * M * (8.0 * C * C + 4.0 * C * C + (proj ? 1.0 * C * C : 0.0));
+      const double bytes = (double)M * C * esize(ex.dt) * (proj ? 3.0 : 2.0) + (double)mlp_fused_stream_bytes(C);
+      ProfScope ps(0, ex.s, flops, bytes, ex.dry(), "M=" + std::to_string(M) + " mlp_fused C=" + std::to_string(C) + " proj=" + std::to_string((int)proj));
+      if (!ex.dry()) {
+        TRY(ex.ws_ok());
+        const int r = launch_mlp_fused(h.p, proj ? out->p : h.p, x.p, t.mlp_stream, t.ff1.bias, t.ff2.bias, t.proj_out.bias,
+                                       igemm_zero_page(), M, C, 1e-5f, proj ? 1 : 0, ex.s);
+        if (r) return fail(r == -2 ? LDMSEG_E_SHAPE : LDMSEG_E_HIP, "launch_mlp_fused failed");
+      }
+    }
+    if (!proj) TRY(ex.conv(t.proj_out, h, nullptr, out, 1, 0, true, nullptr, 0, &x));
+    ws->reset(m);
+    return 0;
   }
   TRY(ex.rowstats(h, 1e-5f, stats));          // norm3, folded into the GEGLU GEMM the same way
   ff = ex.new_act(4 * C, x.H, x.W, false);
@@ -1657,6 +1682,7 @@ int ldmseg_debug_set(int key, int value) {
   static int gn_mode = 0, gn_poll = 100;
   if (key == 10) { gn_mode = value; groupnorm_set_coop(gn_mode, gn_poll); return 0; }
   if (key == 11) { gn_poll = value; groupnorm_set_coop(gn_mode, gn_poll); return 0; }
+  if (key == 12) { mlp_fused_set_mode(value); ++g_plan_epoch; return 0; }   // transformer feed-forward fusion: bit 0 MLP, bit 1 + proj_out
   if (key == 6 || key == 7) { ops_bench_knob(key, value); return 0; }   // ldmseg_bench_igemm: 6 = weight copies rotated, 7 = folded-LN launch   // bits 0-7 ablation flags (LDMSEG_IGEMM_ABLATE builds), bits 8-12 tile policy
   static unsigned long long ts_ptr = 0;                // keys 3/4: low/high half of a device stamp buffer (ablate builds)
   if (key == 3) { ts_ptr = (ts_ptr & 0xffffffff00000000ull) | (unsigned)value; igemm_set_tsbuf((void*)(uintptr_t)ts_ptr); return 0; }
@@ -1668,6 +1694,7 @@ int ldmseg_debug_get(int key) {
   if (key == 1) return igemm_get_dbg();
   if (key == -1) return igemm_default_dbg();     // the shipped value of key 1
   if (key == 9) return igemm_get_cm_mode();
+  if (key == 12) return mlp_fused_get_mode();
   if (key == 10) { const long long n = gn_coop_fallbacks(nullptr); return n > 0x7fffffffll ? 0x7fffffff : (int)n; }   // ring regions (ldmseg_op_* launches)
   return 0;
 }

@@ -1179,6 +1179,7 @@ int dispatch(const IgemmParams& p, hipStream_t s) {
 // allocates + clears this device's zero page now (otherwise the first launch does it: a hipMalloc + a synchronous memset,
 // which a forward that promised not to allocate - ldmseg_unet_reserve - must not hit)
 int igemm_warm() { return zero_page() ? 0 : -3; }
+const void* igemm_zero_page() { return zero_page(); }
 void igemm_set_tsbuf(void* b) { g_tsbuf = b; }
 void igemm_force_cfg(int cfg) { g_force_cfg = cfg; }
 void igemm_set_dbg(int f) { g_dbg = f & 0xff; g_big = (f >> 8) & 63; }   // bits 8-13 select the tile policy

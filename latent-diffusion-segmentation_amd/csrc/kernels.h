@@ -157,6 +157,19 @@ int launch_layernorm(const void* x, void* y, const float* gamma, const float* be
 // self-attention on fused qkv [B, N, 3C] (q | k | v, channel = head*d + i) -> out [B, N, C]
 int launch_attention(const void* qkv, void* out, int B, int N, int C, int heads, int dtype, hipStream_t s);
 
+// Row-local fusion of the transformer feed-forward at the 320-channel level (tfuse.hip): LayerNorm_3 -> GEGLU -> ff.net.2 (+h)
+// [-> proj_out (+x)] in one launch.  mlp_fused_ok: the shape / dtype has the kernel and the mode (debug key 12) allows it.
+bool mlp_fused_ok(int C, int dtype);
+bool mlp_fused_proj();                      // mode bit 1: proj_out rides along
+void mlp_fused_set_mode(int m);             // bit 0: fuse norm3 -> GEGLU -> ff.net.2; bit 1: + proj_out  (default 3)
+int mlp_fused_get_mode();
+size_t mlp_fused_stream_bytes(int C);
+// w1: packed GEGLU weights [8C][C] (16-row value | gate interleave, gamma folded in), w2: [C][4C], wp: proj_out [C][C]; bf16
+int launch_pack_mlp_stream(const void* w1, const void* w2, const void* wp, void* out, int C, hipStream_t s);
+int launch_mlp_fused(const void* h, void* out, const void* x2, const void* stream, const float* bias1, const float* bias2,
+                     const float* bias3, const void* zeros, int M, int C, float eps, int proj, hipStream_t s);
+const void* igemm_zero_page();              // >= 64 KB of zeros on the current device (igemm's padding page)
+
 // per-row (mean, rstd) of [M][C] (LayerNorm statistics, two-pass centred variance) -> stats [M][2] f32
 int launch_rowstats(const void* x, float* stats, int M, int C, float eps, int dtype, hipStream_t s);
 // out[r][k] = colscale[k] * (src_row[r] >= 0 ? w[src_row[r]][k] : 0)   (colscale null = 1)

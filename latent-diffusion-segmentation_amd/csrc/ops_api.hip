@@ -536,6 +536,99 @@ int ldmseg_op_ln_linear(const float* x, const float* gamma, const float* beta, c
   return 0;
 }
 
+// The tail of a transformer block on [M, C] token rows (diffusers BasicTransformerBlock + Transformer2DModel.proj_out,
+// /root/reference/ldmseg/models/unet.py:401-425):
+//     h2  = h + F.linear(GEGLU(F.linear(F.layer_norm(h, (C,), gamma, beta, eps), w1, b1)), w2, b2)
+//     out = F.linear(h2, wp, bp) + x
+// mode 0: the unfused launches (rowstats + folded-LayerNorm GEGLU GEMM + ff.net.2 GEMM + proj_out GEMM); 1: the row-local
+// fused kernel for the feed-forward (tfuse.hip) + proj_out GEMM; 3: everything in the fused kernel.  bf16, C = 320 for 1 / 3.
+// time_iters > 0 also times the chosen path (us per call of the whole tail).
+int ldmseg_op_transformer_ff(const float* h, const float* x, const float* gamma, const float* beta, const float* w1, const float* b1,
+                             const float* w2, const float* b2, const float* wp, const float* bp, int M, int C, float eps, int dtype,
+                             int mode, float* out, int time_iters, float* us_per_call, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  Temp t;
+  if (C % bke(dtype) || (mode != 0 && (dtype != DT_BF16 || !mlp_fused_stream_bytes(C)))) return -2;
+  const int N1 = 8 * C;
+  void* hp = t.get((size_t)M * C * es(dtype));
+  void* h0 = t.get((size_t)M * C * es(dtype));
+  void* xp = t.get((size_t)M * C * es(dtype));
+  void* op = t.get((size_t)M * C * es(dtype));
+  to_dev_dtype(h, h0, (size_t)M * C, dtype, s);
+  to_dev_dtype(x, xp, (size_t)M * C, dtype, s);
+  std::vector<int> map(N1), ident(C);
+  for (int r = 0; r < N1; ++r) { const int blk = r / 32, q = r % 32; map[r] = (q < 16) ? blk * 16 + q : 4 * C + blk * 16 + (q - 16); }
+  for (int r = 0; r < C; ++r) ident[r] = r;
+  int* dmap = (int*)t.get(N1 * sizeof(int));
+  int* dident = (int*)t.get(C * sizeof(int));
+  (void)hipMemcpy(dmap, map.data(), N1 * sizeof(int), hipMemcpyHostToDevice);
+  (void)hipMemcpy(dident, ident.data(), C * sizeof(int), hipMemcpyHostToDevice);
+  void* w1p = t.get((size_t)N1 * C * es(dtype));
+  void* w1b = t.get((size_t)N1 * C * sizeof(float));
+  float* pb = (float*)t.get(N1 * sizeof(float));
+  float* c1 = (float*)t.get(N1 * sizeof(float));
+  float* c2 = (float*)t.get(N1 * sizeof(float));
+  if (launch_repack_rows_scaled(w1, w1p, dmap, N1, C, gamma, dtype, s)) return -3;
+  if (launch_repack_rows_scaled(w1, w1b, dmap, N1, C, beta, DT_F32, s)) return -3;
+  if (launch_repack_rows(b1, pb, dmap, N1, 1, DT_F32, s)) return -3;
+  if (launch_rowsum(w1p, nullptr, c1, N1, C, dtype, s)) return -3;
+  if (launch_rowsum(w1b, pb, c2, N1, C, DT_F32, s)) return -3;
+  void* w2p = t.get((size_t)C * 4 * C * es(dtype));
+  void* wpp = t.get((size_t)C * C * es(dtype));
+  to_dev_dtype(w2, w2p, (size_t)C * 4 * C, dtype, s);        // Linear weights are already [N][K]
+  to_dev_dtype(wp, wpp, (size_t)C * C, dtype, s);
+  float* b2d = (float*)t.get(C * sizeof(float));
+  float* bpd = (float*)t.get(C * sizeof(float));
+  (void)hipMemcpyAsync(b2d, b2, C * sizeof(float), hipMemcpyDeviceToDevice, s);
+  (void)hipMemcpyAsync(bpd, bp, C * sizeof(float), hipMemcpyDeviceToDevice, s);
+  void* stream_w = nullptr;
+  if (mode != 0) {
+    stream_w = t.get(mlp_fused_stream_bytes(C));
+    if (launch_pack_mlp_stream(w1p, w2p, wpp, stream_w, C, s)) return -3;
+  }
+  float* stats = (float*)t.get((size_t)M * 2 * sizeof(float));
+  void* ff = t.get((size_t)M * 4 * C * es(dtype));
+  if (igemm_warm()) return -3;
+  auto gemm = [&](const void* src, int K, const void* W, int N, int nvalid, const float* bias, const void* resid, void* o, int epi,
+                  const float* rs, const float* cc1) -> int {
+    IgemmParams p;
+    p.src0 = src; p.C0 = K; p.B = 1; p.Hi = p.Ho = M; p.Wi = p.Wo = 1;
+    p.M = M; p.N = N; p.n_valid = nvalid; p.W = W; p.bias = bias; p.rowstats = rs; p.c1 = cc1;
+    p.resid = resid; p.ldr = C; p.out = o; p.ldo = nvalid; p.epi = epi;
+    const int sp = igemm_plan_splits(p, dtype);
+    if (sp > 1) { p.splits = sp; p.partial = (float*)t.get((size_t)sp * M * N * sizeof(float)); }
+    return launch_igemm(p, dtype, s);
+  };
+  auto run = [&]() -> int {
+    (void)hipMemcpyAsync(hp, h0, (size_t)M * C * es(dtype), hipMemcpyDeviceToDevice, s);   // the tail updates h in place
+    if (mode == 0) {
+      if (int r = launch_rowstats(hp, stats, M, C, eps, dtype, s)) return r;
+      if (int r = gemm(hp, C, w1p, N1, 4 * C, c2, nullptr, ff, EPI_GEGLU, stats, c1)) return r;
+      if (int r = gemm(ff, 4 * C, w2p, C, C, b2d, hp, hp, EPI_STORE, nullptr, nullptr)) return r;
+      return gemm(hp, C, wpp, C, C, bpd, xp, op, EPI_STORE, nullptr, nullptr);
+    }
+    const int proj = (mode & 2) ? 1 : 0;
+    if (int r = launch_mlp_fused(hp, proj ? op : hp, xp, stream_w, c2, b2d, bpd, igemm_zero_page(), M, C, eps, proj, s)) return r;
+    return proj ? 0 : gemm(hp, C, wpp, C, C, bpd, xp, op, EPI_STORE, nullptr, nullptr);
+  };
+  if (int r = run()) return r;
+  if (time_iters > 0 && us_per_call) {
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    for (int i = 0; i < 2; ++i) (void)run();
+    (void)hipEventRecord(e0, s);
+    for (int i = 0; i < time_iters; ++i) (void)run();
+    (void)hipEventRecord(e1, s);
+    (void)hipEventSynchronize(e1);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    *us_per_call = 1e3f * ms / time_iters;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  }
+  from_dev_dtype(op, out, (size_t)M * C, dtype, s);
+  return 0;
+}
+
 // the same attention on the fp8 (e4m3) operand path of the bf16 mode (attention_fp8.hip): head dim 40 or 80
 int ldmseg_op_attention_fp8(const float* qkv, int B, int N, int C, int heads, float* out, int time_iters, float* us_per_launch,
                             void* stream) {

@@ -774,3 +774,72 @@ def test_fastdiv_on_device(L):
         assert L.lib().ldmseg_op_fastdiv(C.c_void_p(nd.data_ptr()), nd.numel(), d, C.c_void_p(q.data_ptr()), None) == 0
         torch.cuda.synchronize()
         assert torch.equal(q.cpu().to(torch.int64), n // d), d
+
+
+# ------------------------------------------------------------------ row-local fused transformer feed-forward (tfuse.hip)
+def _ff_case(M, Cc, seed):
+    g = torch.Generator().manual_seed(seed)
+    h = torch.randn(M, Cc, generator=g) * 1.5 + 0.3
+    h[:, ::7] += 2.0                                     # rows with a mean: the LayerNorm has something to remove
+    x = torch.randn(M, Cc, generator=g)
+    gamma = 1 + 0.2 * torch.randn(Cc, generator=g)
+    beta = 0.2 * torch.randn(Cc, generator=g)
+    w1 = torch.randn(8 * Cc, Cc, generator=g) / Cc ** 0.5
+    b1 = 0.2 * torch.randn(8 * Cc, generator=g)
+    w2 = torch.randn(Cc, 4 * Cc, generator=g) / (4 * Cc) ** 0.5
+    b2 = 0.2 * torch.randn(Cc, generator=g)
+    wp = torch.randn(Cc, Cc, generator=g) / Cc ** 0.5
+    bp = 0.2 * torch.randn(Cc, generator=g)
+    return h, x, gamma, beta, w1, b1, w2, b2, wp, bp
+
+
+def _ff_ref(h, x, gamma, beta, w1, b1, w2, b2, wp, bp, eps=1e-5):
+    """torch fp32 on the bf16-rounded operands, the arithmetic of oracle/unet.py::transformer (ff + proj_out)."""
+    hr, xr = bf16_round(h), bf16_round(x)
+    n = F.layer_norm(hr, (h.shape[1],), gamma, beta, eps)
+    a, gate = F.linear(n, w1, b1).chunk(2, dim=-1)
+    h2 = F.linear(a * F.gelu(gate), bf16_round(w2), b2) + hr
+    return F.linear(h2, bf16_round(wp), bp) + xr
+
+
+def _ff_run(L, case, M, Cc, mode, dt=BF16, iters=0):
+    out = torch.empty(M, Cc, device="cuda")
+    keep = [dev(t) for t in case]
+    us = C.c_float(0)
+    r = L.lib().ldmseg_op_transformer_ff(*[P(t) for t in keep], M, Cc, 1e-5, dt, mode, P(out), iters, C.byref(us), None)
+    assert r == 0, (r, L.lib().ldmseg_last_error())
+    torch.cuda.synchronize()
+    return out.cpu(), us.value
+
+
+@pytest.mark.parametrize("M", [128, 300, 1000, 4096, 32768])
+def test_transformer_ff_fused_vs_torch_and_unfused(L, M):
+    """LayerNorm_3 -> GEGLU -> ff.net.2 (+h) -> proj_out (+x) of the 320-channel transformers in ONE launch (modes 1 / 3)
+    against torch on the same bf16-rounded operands and against the unfused launches (mode 0): one tile, ragged tiles, and
+    the configs[1] size (M = 8 x 64 x 64).  The hidden tensor is rounded to bf16 in every variant; the fused kernel rounds
+    the LayerNorm output to bf16 as well (the unfused path folds the norm into the GEMM), hence a bf16-level bound."""
+    Cc = 320
+    case = _ff_case(M, Cc, 1000 + M)
+    ref = _ff_ref(*case)
+    outs = {m: _ff_run(L, case, M, Cc, m)[0] for m in (0, 1, 3)}
+    for m, o in outs.items():
+        assert torch.isfinite(o).all(), m
+        e = rel_err(o, ref)
+        l2 = float((o.double() - ref.double()).norm() / ref.double().norm())
+        assert e < 3e-2 and l2 < 6e-3, (M, m, e, l2)
+    # fused against unfused: both are bf16 pipelines of the same math
+    l2 = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    assert l2(outs[1], outs[0]) < 6e-3 and l2(outs[3], outs[0]) < 6e-3
+    # deterministic
+    assert torch.equal(_ff_run(L, case, M, Cc, 3)[0], outs[3])
+
+
+def test_transformer_ff_fused_large_mean_rows(L):
+    """Rows with a mean 100x their deviation: the in-tile LayerNorm is two-pass (centred variance), so nothing cancels."""
+    M, Cc = 256, 320
+    case = list(_ff_case(M, Cc, 5))
+    case[0] = case[0] * 0.05 + 8.0
+    ref = _ff_ref(*case)
+    for m in (1, 3):
+        o = _ff_run(L, case, M, Cc, m)[0]
+        assert float((o.double() - ref.double()).norm() / ref.double().norm()) < 1.5e-2, m
