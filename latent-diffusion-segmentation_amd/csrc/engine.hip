@@ -723,7 +723,7 @@ int run_transformer(Exec& ex, const TransformerW& t, const Act& x, Act* out) {
       if (!ex.dry()) {
         TRY(ex.ws_ok());
         const int r = launch_mlp_fused(h.p, proj ? out->p : h.p, x.p, t.mlp_stream, t.ff1.bias, t.ff2.bias, t.proj_out.bias,
-                                       igemm_zero_page(), M, C, 1e-5f, proj ? 1 : 0, ex.s);
+                                       igemm_zero_page(), M, C, 1e-5f, proj ? 1 : 0, N, ex.s);
         if (r) return fail(r == -2 ? LDMSEG_E_SHAPE : LDMSEG_E_HIP, "launch_mlp_fused failed");
       }
     }
@@ -1682,7 +1682,8 @@ int ldmseg_debug_set(int key, int value) {
   static int gn_mode = 0, gn_poll = 100;
   if (key == 10) { gn_mode = value; groupnorm_set_coop(gn_mode, gn_poll); return 0; }
   if (key == 11) { gn_poll = value; groupnorm_set_coop(gn_mode, gn_poll); return 0; }
-  if (key == 12) { mlp_fused_set_mode(value); ++g_plan_epoch; return 0; }   // transformer feed-forward fusion: bit 0 MLP, bit 1 + proj_out
+  if (key == 12) { mlp_fused_set_mode(value); ++g_plan_epoch; return 0; }
+  if (key == 13) { mlp_fused_set_dbg(value); return 0; }   // bit 8: no start-chunk rotation (bits 0-7: ablate builds)   // transformer feed-forward fusion: bit 0 MLP, bit 1 + proj_out
   if (key == 6 || key == 7) { ops_bench_knob(key, value); return 0; }   // ldmseg_bench_igemm: 6 = weight copies rotated, 7 = folded-LN launch   // bits 0-7 ablation flags (LDMSEG_IGEMM_ABLATE builds), bits 8-12 tile policy
   static unsigned long long ts_ptr = 0;                // keys 3/4: low/high half of a device stamp buffer (ablate builds)
   if (key == 3) { ts_ptr = (ts_ptr & 0xffffffff00000000ull) | (unsigned)value; igemm_set_tsbuf((void*)(uintptr_t)ts_ptr); return 0; }

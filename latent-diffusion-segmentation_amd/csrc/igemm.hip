@@ -1194,6 +1194,7 @@ std::string igemm_dispatch_name(const IgemmDispatch& d) {
   return buf;
 }
 void igemm_log_enable(int on) { g_log_on = on != 0; if (on) g_log.clear(); }
+void igemm_log_note(const char* name) { if (g_log_on) g_log.insert(name); }   // kernels of the GEMM family that are not igemm_kernel (tfuse.hip)
 std::string igemm_log_read() {
   std::string out;
   for (const auto& e : g_log) { out += e; out += '\n'; }

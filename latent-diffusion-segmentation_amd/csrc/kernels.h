@@ -107,6 +107,7 @@ struct IgemmDispatch { int dtype, bm, bn, wm, wn, nst, pipe, ldr, splits, grid, 
 IgemmDispatch igemm_last_dispatch();
 std::string igemm_dispatch_name(const IgemmDispatch& d);
 void igemm_log_enable(int on);      // start (and clear) / stop recording the distinct instantiations launched
+void igemm_log_note(const char* name);   // recorded while logging is on (the fused feed-forward kernel: "mlp_fused<bf16,proj=P>")
 std::string igemm_log_read();       // newline-separated   // ablation flags (profiling only)   // K-loop ring depth (2, 3, 4) - tuning knob
 // tile the launcher would pick (for weight padding): N tile size for a given N.
 int igemm_pick_bn(int n_real, int epi);
@@ -167,7 +168,8 @@ size_t mlp_fused_stream_bytes(int C);
 // w1: packed GEGLU weights [8C][C] (16-row value | gate interleave, gamma folded in), w2: [C][4C], wp: proj_out [C][C]; bf16
 int launch_pack_mlp_stream(const void* w1, const void* w2, const void* wp, void* out, int C, hipStream_t s);
 int launch_mlp_fused(const void* h, void* out, const void* x2, const void* stream, const float* bias1, const float* bias2,
-                     const float* bias3, const void* zeros, int M, int C, float eps, int proj, hipStream_t s);
+                     const float* bias3, const void* zeros, int M, int C, float eps, int proj, int rows_per_image, hipStream_t s);
+void mlp_fused_set_dbg(int flags);          // bit 8: no start-chunk rotation; bits 0-7: phase ablation (LDMSEG_TFUSE_ABLATE builds only)
 const void* igemm_zero_page();              // >= 64 KB of zeros on the current device (igemm's padding page)
 
 // per-row (mean, rstd) of [M][C] (LayerNorm statistics, two-pass centred variance) -> stats [M][2] f32

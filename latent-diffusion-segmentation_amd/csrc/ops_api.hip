@@ -548,6 +548,7 @@ int ldmseg_op_transformer_ff(const float* h, const float* x, const float* gamma,
                              int mode, float* out, int time_iters, float* us_per_call, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   Temp t;
+  const int rows_per_image = (M % 4096 == 0) ? 4096 : 0;      // (tiles rotate their chunk sweep by the index inside a 64x64 image)
   if (C % bke(dtype) || (mode != 0 && (dtype != DT_BF16 || !mlp_fused_stream_bytes(C)))) return -2;
   const int N1 = 8 * C;
   void* hp = t.get((size_t)M * C * es(dtype));
@@ -608,7 +609,7 @@ int ldmseg_op_transformer_ff(const float* h, const float* x, const float* gamma,
       return gemm(hp, C, wpp, C, C, bpd, xp, op, EPI_STORE, nullptr, nullptr);
     }
     const int proj = (mode & 2) ? 1 : 0;
-    if (int r = launch_mlp_fused(hp, proj ? op : hp, xp, stream_w, c2, b2d, bpd, igemm_zero_page(), M, C, eps, proj, s)) return r;
+    if (int r = launch_mlp_fused(hp, proj ? op : hp, xp, stream_w, c2, b2d, bpd, igemm_zero_page(), M, C, eps, proj, rows_per_image, s)) return r;
     return proj ? 0 : gemm(hp, C, wpp, C, C, bpd, xp, op, EPI_STORE, nullptr, nullptr);
   };
   if (int r = run()) return r;

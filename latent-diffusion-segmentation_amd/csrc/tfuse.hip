@@ -83,7 +83,19 @@ struct MlpFusedParams {
   const void* zeros;       // >= 16 B of zeros
   int M, nchunks;
   float eps;
+  int rot_tiles;           // > 0: tiles per image; the workgroup starts its hidden-chunk sweep at a chunk derived from its tile index inside the image
+  int dbg;                 // -DLDMSEG_TFUSE_ABLATE builds: phase-ablation flags (results are wrong when != 0)
 };
+#ifdef LDMSEG_TFUSE_ABLATE
+#define TFDBG(p, bit) ((LDMSEG_TFUSE_ABLATE) & (bit))     // compile-time mask: run-time flags cost registers (the 168-budget kernel spilled)
+__device__ unsigned long long g_tf_ts[64];
+#define TFSTAMP(slot) if (blockIdx.x == 0 && threadIdx.x == 0) g_tf_ts[slot] = wall_clock64();
+#define TFSTAMP_L(slot, cond) if ((cond) && blockIdx.x == 0 && threadIdx.x == 512) g_tf_ts[slot] = wall_clock64();
+#else
+#define TFDBG(p, bit) 0
+#define TFSTAMP(slot)
+#define TFSTAMP_L(slot, cond)
+#endif
 
 template <bool PROJ>
 __global__ __launch_bounds__(768, 3) void mlp_fused_kernel(const MlpFusedParams p) {
@@ -95,6 +107,10 @@ __global__ __launch_bounds__(768, 3) void mlp_fused_kernel(const MlpFusedParams 
   const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)smem);
   // units of the weight stream, in consumption order: per chunk 5 x W1 tile (4 pieces per loader wave) + W2 (10); PROJ: 10 x 5
   const int nunits = p.nchunks * 6 + (PROJ ? 2 * kKT : 0);
+  // Every workgroup consumes the same stream; started at the same chunk they would all ask the L2 for the same lines at the
+  // same moment.  The sweep over the hidden chunks is a sum, so each tile starts it elsewhere (a function of the tile's index
+  // INSIDE its image only: an image's result does not depend on its position in the batch).
+  const int start = p.rot_tiles > 0 ? (int)(((unsigned)blockIdx.x % (unsigned)p.rot_tiles) * 7u % (unsigned)p.nchunks) : 0;
 
   if (wave_id >= 8) {
     // ================= loader waves: the row tile, then the weight stream through the ring =================
@@ -110,34 +126,63 @@ __global__ __launch_bounds__(768, 3) void mlp_fused_kernel(const MlpFusedParams 
         glds16(src, __builtin_amdgcn_readfirstlane(lds0 + kt * (kBM * 128) + rg * 1024));
       }
     }
-    auto share = [&](int u) -> int { return (u < p.nchunks * 6) ? ((u % 6 == 5) ? 10 : 4) : 5; };
-    int total = 0;
-    for (int u = 0; u < nunits; ++u) total += share(u);               // pieces this wave issues in all
-    int iss = 0, fre = 0;                                             // issued / freed pieces of this wave's share
+    // This wave's share of a unit's pieces: 4 (W1 tile), 10 (W2 chunk), 5 (proj_out unit); its share of the ring: 16.
+    // What the first version got wrong (s_memrealtime stamps, tools/ff_ablate.py): the compute waves sat at every barrier
+    // waiting for THIS loop - bookkeeping with runtime divisions, the issue of the next pieces in front of the barrier, and a
+    // loader wave gets an issue slot only every ~12 cycles next to two busy compute waves of its SIMD.  Now: raised priority,
+    // pointer increments instead of index arithmetic, and per step  wait(unit t+1 landed) -> barrier -> issue into the space
+    // unit t just freed  (the issue runs in the shadow of the compute waves' next step).
+    __builtin_amdgcn_s_setprio(3);
+    const int nchunk_units = p.nchunks * 6;
+    const int chunk_pieces = p.nchunks * 30;                          // this wave's pieces of the chunk region (circular: rotation)
+    int left = chunk_pieces + (PROJ ? 2 * kKT * 5 : 0);               // pieces this wave still has to issue
+    int iss = 0;                                                      // issued so far
     const unsigned voff = (unsigned)lane * 16u;
-    auto issue = [&]() __attribute__((always_inline)) {
-      while (iss - fre < 16 && iss < total) {
-        const unsigned g = (unsigned)(iss * 4 + lw);                  // global piece index
-        const unsigned char* src = p.stream + (size_t)g * 1024;
-        const unsigned long long su = (unsigned long long)(uintptr_t)src;
-        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)su), hi = __builtin_amdgcn_readfirstlane((unsigned)(su >> 32));
-        glds16_sbase(voff, (const void*)(uintptr_t)(((unsigned long long)hi << 32) | lo),
-                     __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(kXT + kHT) + ((g * 1024u) & (unsigned)(kRing - 1))));
+    const unsigned char* src = p.stream + ((size_t)start * 120 + lw) * 1024;
+    int to_wrap = chunk_pieces - start * 30;                          // pieces until the source wraps to chunk 0 / moves on to proj_out
+    bool in_chunks = true;
+    unsigned dst = (unsigned)lw * 1024u;                              // ring offset of the next piece
+    auto issue_n = [&](int n) __attribute__((always_inline)) {
+      for (int i = 0; i < n && left > 0; ++i) {
+        if (!TFDBG(p, 1)) {
+          const unsigned long long su = (unsigned long long)(uintptr_t)src;
+          const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)su), hi = __builtin_amdgcn_readfirstlane((unsigned)(su >> 32));
+          glds16_sbase(voff, (const void*)(uintptr_t)(((unsigned long long)hi << 32) | lo),
+                       __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(kXT + kHT) + dst));
+        }
+        src += 4096;
+        dst = (dst + 4096u) & (unsigned)(kRing - 1);
         ++iss;
+        --left;
+        if (--to_wrap == 0) {
+          if (in_chunks && iss < chunk_pieces) { src = p.stream + (size_t)lw * 1024; to_wrap = chunk_pieces - iss; }   // chunk 0 follows the last chunk
+          else { src = p.stream + ((size_t)p.nchunks * 120 + lw) * 1024; in_chunks = false; to_wrap = 0x7fffffff; }     // proj_out region
+        }
       }
     };
-    issue();
+    issue_n(16);
     wait_pieces(iss);                       // the row tile has landed (its pieces were issued first)
     __syncthreads();                        // A: tile ready for the LayerNorm pass
-    int land = share(0);                    // cumulative share through the unit that must have landed next
+    int land = 4;                           // this wave's pieces through the unit that must have landed next (unit 0: a W1 tile)
     wait_pieces(iss - land);
     __syncthreads();                        // B: tile normalised, unit 0 landed
+    int pos = 0;                            // position of unit t inside its chunk (5 = the W2 chunk)
     for (int t = 0; t < nunits; ++t) {
-      if (PROJ && t == p.nchunks * 6) __syncthreads();   // pairs with the barrier between the ff epilogue and proj_out's K loop
-      if (t > 0) fre += share(t - 1);       // the compute waves passed barrier t-1: unit t-1 is free
-      issue();
-      if (t + 1 < nunits) { land += share(t + 1); wait_pieces(iss - land); }
-      __syncthreads();                      // end of step t
+      if (PROJ && t == nchunk_units) asm volatile("s_barrier" ::: "memory");   // pairs with the barrier between the ff epilogue and proj_out's K loop
+      const int sh_t = (t < nchunk_units) ? (pos == 5 ? 10 : 4) : 5;
+      if (t + 1 < nunits) {
+        land += (t + 1 < nchunk_units) ? (pos == 4 ? 10 : 4) : 5;   // share of unit t+1
+        const int n = iss - land;
+        if (n == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");           // (the steady state of the chunk loop: 8, 8, 8, 8, 2, 2)
+        else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else wait_pieces(n);
+      }
+      TFSTAMP_L(24 + (t - 30) * 3 + 0, t >= 30 && t < 36)
+      asm volatile("s_barrier" ::: "memory");           // end of step t: unit t+1 has landed, unit t is free
+      TFSTAMP_L(24 + (t - 30) * 3 + 1, t >= 30 && t < 36)
+      issue_n(sh_t);
+      TFSTAMP_L(24 + (t - 30) * 3 + 2, t >= 30 && t < 36)
+      pos = (pos == 5) ? 0 : pos + 1;
     }
     return;
   }
@@ -152,7 +197,9 @@ __global__ __launch_bounds__(768, 3) void mlp_fused_kernel(const MlpFusedParams 
   const int fr_c0 = ((lg) ^ (lane & 7)) * 16;
   const int fr_c1 = ((lg + 4) ^ (lane & 7)) * 16;
 
+  TFSTAMP(0)
   __syncthreads();                          // A: the row tile has landed
+  TFSTAMP(1)
   {
     // ---- LayerNorm of the tile's rows in place (no affine: gamma / beta live in the GEGLU weights and bias): 4 lanes per
     // row, 10 x 16 B each; two-pass mean / centred variance like launch_rowstats
@@ -192,7 +239,9 @@ __global__ __launch_bounds__(768, 3) void mlp_fused_kernel(const MlpFusedParams 
       *(uint4*)(rowp + (j >> 3) * (kBM * 128) + (((j & 7) ^ (r & 7)) << 4)) = Chunk<bf16_t>::pack(y);
     }
   }
+  TFSTAMP(2)
   __syncthreads();                          // B: normalised tile visible, unit 0 landed
+  TFSTAMP(3)
 
   f32x4 acc2[5][4];
 #pragma unroll
@@ -203,12 +252,14 @@ __global__ __launch_bounds__(768, 3) void mlp_fused_kernel(const MlpFusedParams 
   unsigned uoff = 0;                        // ring offset of the current unit
   const unsigned char* xrow = XT + (wm * 64) * 128 + fr_row;
   const unsigned char* hrow = HT + (wm * 64) * 128 + fr_row;
-  for (int c = 0; c < p.nchunks; ++c) {
+  int c = start;
+  for (int ci = 0; ci < p.nchunks; ++ci, c = (c + 1 == p.nchunks) ? 0 : c + 1) {
     f32x4 acc1[2][4];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int b = 0; b < 4; ++b) acc1[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (ci == 5) { TFSTAMP(11) }
     const float* bp = p.bias1 + c * 128 + wn * 32 + lg * 4;
     const f32x4 bv = *(const f32x4*)bp, bg = *(const f32x4*)(bp + 16);
 #pragma unroll 1
@@ -221,14 +272,27 @@ __global__ __launch_bounds__(768, 3) void mlp_fused_kernel(const MlpFusedParams 
       for (int kg = 0; kg < 2; ++kg) {
         const int co = kg ? fr_c1 : fr_c0;
         uint4 xf[4], wf[2];
-        wf[0] = *(const uint4*)(w0 + co);
+        if (!TFDBG(p, 16)) {
+          wf[0] = *(const uint4*)(w0 + co);
 #pragma unroll
-        for (int b = 0; b < 4; ++b) xf[b] = *(const uint4*)(xs + b * 2048 + co);
-        wf[1] = *(const uint4*)(w1 + co);
+          for (int b = 0; b < 4; ++b) xf[b] = *(const uint4*)(xs + b * 2048 + co);
+          wf[1] = *(const uint4*)(w1 + co);
+        } else {
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+          for (int b = 0; b < 4; ++b) xf[b] = make_uint4(lane, b, kt, 1);
+          wf[0] = wf[1] = make_uint4(lane, 3, kt, 7);
+        }
+        if (!TFDBG(p, 4)) {
 #pragma unroll
-          for (int b = 0; b < 4; ++b) mma_kgroup<bf16_t>(wf[a], xf[b], acc1[a][b]);
+          for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) mma_kgroup<bf16_t>(wf[a], xf[b], acc1[a][b]);
+        } else {
+#pragma unroll
+          for (int a = 0; a < 2; ++a) asm volatile("" ::"v"(wf[a].x), "v"(wf[a].w));
+#pragma unroll
+          for (int b = 0; b < 4; ++b) asm volatile("" ::"v"(xf[b].x), "v"(xf[b].w));
+        }
       }
       if (kt == kKT - 1) {
         // GEGLU on the finished chunk: value and gate of 16 hidden columns sit in the same lane.  The bf16 result is this
@@ -236,33 +300,54 @@ __global__ __launch_bounds__(768, 3) void mlp_fused_kernel(const MlpFusedParams 
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
           const f32x4 av = acc1[0][b] + bv, gv = acc1[1][b] + bg;
-          const f32x4 o = av * gelu_erf_bf16_f4(gv);
+          const f32x4 o = TFDBG(p, 2) ? av * gv : av * gelu_erf_bf16_f4(gv);
           const int row = wm * 64 + b * 16 + lq;
           const int ch = wn * 2 + (lg >> 1);
-          *(uint2*)(HT + row * 128 + ((ch ^ (row & 7)) << 4) + (lg & 1) * 8) = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+          if (!TFDBG(p, 64)) *(uint2*)(HT + row * 128 + ((ch ^ (row & 7)) << 4) + (lg & 1) * 8) = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+          else asm volatile("" ::"v"(o[0]), "v"(o[3]));
         }
       }
       __syncthreads();
       uoff = (uoff + kW1Tile) & (unsigned)(kRing - 1);
+      if (ci == 5) { TFSTAMP(16 + kt) }
     }
+    if (ci == 5) { TFSTAMP(12) }
     // ---- acc2 += H . W2_chunk^T : rows of W2 for this wave [wn*80, wn*80 + 80)
 #pragma unroll
     for (int kg = 0; kg < 2; ++kg) {
       const int co = kg ? fr_c1 : fr_c0;
       uint4 hf[4], wf[5];
+      if (!TFDBG(p, 32)) {
 #pragma unroll
-      for (int b = 0; b < 4; ++b) hf[b] = *(const uint4*)(hrow + b * 2048 + co);
+        for (int b = 0; b < 4; ++b) hf[b] = *(const uint4*)(hrow + b * 2048 + co);
 #pragma unroll
-      for (int a = 0; a < 5; ++a)
-        wf[a] = *(const uint4*)(RING + ((uoff + (unsigned)(wn * 80 + a * 16) * 128u) & (unsigned)(kRing - 1)) + fr_row + co);
+        for (int a = 0; a < 5; ++a)
+          wf[a] = *(const uint4*)(RING + ((uoff + (unsigned)(wn * 80 + a * 16) * 128u) & (unsigned)(kRing - 1)) + fr_row + co);
+      } else {
 #pragma unroll
-      for (int a = 0; a < 5; ++a)
+        for (int b = 0; b < 4; ++b) hf[b] = make_uint4(lane, b, 2, 1);
 #pragma unroll
-        for (int b = 0; b < 4; ++b) mma_kgroup<bf16_t>(wf[a], hf[b], acc2[a][b]);
+        for (int a = 0; a < 5; ++a) wf[a] = make_uint4(lane, a, 5, 7);
+      }
+      if (!TFDBG(p, 8)) {
+#pragma unroll
+        for (int a = 0; a < 5; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) mma_kgroup<bf16_t>(wf[a], hf[b], acc2[a][b]);
+      } else {
+#pragma unroll
+        for (int a = 0; a < 5; ++a) asm volatile("" ::"v"(wf[a].x), "v"(wf[a].w));
+#pragma unroll
+        for (int b = 0; b < 4; ++b) asm volatile("" ::"v"(hf[b].x), "v"(hf[b].w));
+      }
     }
     __syncthreads();
     uoff = (uoff + kW2Unit) & (unsigned)(kRing - 1);
+    if (ci == 0) { TFSTAMP(4) }
+    if (ci == 5) { TFSTAMP(13) }
+    if (ci == 9) { TFSTAMP(5) }
   }
+  TFSTAMP(6)
 
   // ================= ff.net.2 epilogue: + bias + h =================
   const int nl = wn * 80 + lg * 4;          // this lane's first column of fragment 0 (+ a*16)
@@ -334,7 +419,9 @@ __global__ __launch_bounds__(768, 3) void mlp_fused_kernel(const MlpFusedParams 
             make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
       }
     }
+    TFSTAMP(7)
     __syncthreads();                        // the new tile is visible to every wave
+    TFSTAMP(8)
     // proj_out on 4 x 2 waves per N half (units are [160 rows of half h][128 B]): wave tile 32 rows x 80 columns per half
     const int pm = wave_id >> 1, pn = wave_id & 1;
     f32x4 acc3[2][5][2];
@@ -368,6 +455,7 @@ __global__ __launch_bounds__(768, 3) void mlp_fused_kernel(const MlpFusedParams 
         uoff = (uoff + kPUnit) & (unsigned)(kRing - 1);
       }
     }
+    TFSTAMP(9)
     // epilogue of proj_out: + bp + x2, row-major through the hidden-chunk / ring area (every unit has been consumed and
     // every wave is past its last fragment read: the barrier above)
     constexpr int SROW = 80 * 4 + 16, CPR = 10, NCH = 160, NI = 3;
@@ -418,6 +506,7 @@ __global__ __launch_bounds__(768, 3) void mlp_fused_kernel(const MlpFusedParams 
       }
     }
   }
+  TFSTAMP(10)
 }
 
 // One 16-byte chunk of the stream per thread.  w1: GEGLU weights [8C][C] in the engine's packed row order (gamma folded in),
@@ -452,6 +541,7 @@ __global__ __launch_bounds__(256) void tf_pack_stream_kernel(const bf16_t* __res
   out[gid] = *(const uint4*)src;
 }
 
+int g_tfuse_dbg = 0;      // phase-ablation flags (LDMSEG_TFUSE_ABLATE builds) | bit 8: no start-chunk rotation
 int g_tfuse_mode = 3;     // bit 0: fuse LayerNorm_3 -> GEGLU -> ff.net.2 (+h); bit 1: also proj_out (+x)
 
 }  // namespace
@@ -459,6 +549,7 @@ int g_tfuse_mode = 3;     // bit 0: fuse LayerNorm_3 -> GEGLU -> ff.net.2 (+h); 
 bool mlp_fused_ok(int C, int dtype) { return (g_tfuse_mode & 1) && C == kC && dtype == DT_BF16; }
 bool mlp_fused_proj() { return (g_tfuse_mode & 2) != 0; }
 void mlp_fused_set_mode(int m) { g_tfuse_mode = m & 3; }
+void mlp_fused_set_dbg(int f) { g_tfuse_dbg = f; }
 int mlp_fused_get_mode() { return g_tfuse_mode; }
 size_t mlp_fused_stream_bytes(int C) { return C == kC ? (size_t)(4 * kC / kHC) * kChunkBytes + (size_t)kKT * kW2Unit : 0; }
 
@@ -472,12 +563,15 @@ int launch_pack_mlp_stream(const void* w1, const void* w2, const void* wp, void*
 
 // h [M][320] bf16 in place (proj = 0: out = h + ff(LN(h)))  or  out = proj_out(h + ff(LN(h))) + x2 (proj = 1)
 int launch_mlp_fused(const void* h, void* out, const void* x2, const void* stream, const float* bias1, const float* bias2,
-                     const float* bias3, const void* zeros, int M, int C, float eps, int proj, hipStream_t s) {
+                     const float* bias3, const void* zeros, int M, int C, float eps, int proj, int rows_per_image, hipStream_t s) {
   if (C != kC || M < 1 || !h || !out || !stream || !bias1 || !bias2 || !zeros || (proj && (!x2 || !bias3))) return -2;
   MlpFusedParams p;
   p.x = (const bf16_t*)h; p.out = (bf16_t*)out; p.x2 = (const bf16_t*)x2;
   p.stream = (const unsigned char*)stream; p.bias1 = bias1; p.bias2 = bias2; p.bias3 = bias3; p.zeros = zeros;
   p.M = M; p.nchunks = 4 * kC / kHC; p.eps = eps;
+  p.dbg = g_tfuse_dbg & 0xff;
+  // start-chunk rotation by the tile's index inside its image (whole tiles per image only; otherwise by nothing)
+  p.rot_tiles = (!(g_tfuse_dbg & 256) && rows_per_image > 0 && rows_per_image % kBM == 0) ? rows_per_image / kBM : 0;
   const dim3 grid((M + kBM - 1) / kBM), block(768);
   static bool attr_set[64] = {};
   int dev = 0;
@@ -487,9 +581,16 @@ int launch_mlp_fused(const void* h, void* out, const void* x2, const void* strea
     (void)hipFuncSetAttribute((const void*)mlp_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
     attr_set[dev] = true;
   }
+  igemm_log_note(proj ? "mlp_fused<bf16,proj=1>" : "mlp_fused<bf16,proj=0>");
   if (proj) hipLaunchKernelGGL(mlp_fused_kernel<true>, grid, block, kLds, s, p);
   else hipLaunchKernelGGL(mlp_fused_kernel<false>, grid, block, kLds, s, p);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
 }  // namespace ldmseg
+
+#ifdef LDMSEG_TFUSE_ABLATE
+extern "C" int ldmseg_debug_tf_stamps(unsigned long long* host, int n) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(ldmseg::g_tf_ts), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -202,6 +202,23 @@ def test_conv_out_shape_vs_oracle(L, dt, cfg):
     assert rel_err(out, ref) < (1e-3 if dt == BF16 else 1e-4)
 
 
+@pytest.mark.parametrize("cfg", CONFIGS, ids=CFG_IDS)
+def test_fused_feed_forward_at_config_shape(L, cfg):
+    """The row-local fused feed-forward kernel (tfuse.hip: LayerNorm_3 -> GEGLU -> ff.net.2 (+h) -> proj_out (+x)) that the
+    bf16 forward runs on the 320-channel level, at this configuration's token count M = B * L * L, against torch on the same
+    bf16-rounded operands (the arithmetic of oracle/unet.py::transformer)."""
+    from test_ops_gpu import _ff_case, _ff_ref, _ff_run
+    B, lat = cfg
+    M = B * lat * lat
+    case = _ff_case(M, 320, 7 + M)
+    ref = _ff_ref(*case)
+    for mode, name in ((3, "mlp_fused<bf16,proj=1>"), (1, "mlp_fused<bf16,proj=0>")):
+        out, _ = _ff_run(L, case, M, 320, mode)
+        l2 = float((out.double() - ref.double()).norm() / ref.double().norm())
+        assert torch.isfinite(out).all() and l2 < 6e-3 and rel_err(out, ref) < 3e-2, (cfg, mode, l2)
+        SEEN[(cfg, BF16)].add(name)
+
+
 @pytest.mark.parametrize("mode,dt", [("bf16", BF16), ("fp32", F32)])
 @pytest.mark.parametrize("cfg", CONFIGS, ids=CFG_IDS)
 def test_every_forward_instantiation_is_oracle_tested(L, unet_sd, cfg, mode, dt):
