@@ -222,6 +222,59 @@ def colormap_golden():
     print("colormap.npz ok", cmap.shape, cmap.dtype)
 
 
+def real_coco_golden():
+    """Two of the reference's own example pairs (data/examples/coco/{rgb_images,panoptic_images}: one portrait 480x640, one
+    landscape 640x427) through the reference's data path: panoptic PNG -> segment ids (coco.py:500-501, the two numpy lines of
+    _load_semseg - the rest of that method needs the COCO annotation json, which the examples do not ship), then the
+    reference's OWN functions, called unbound on a dummy self as in bitcodec_golden(): COCO._remap_labels_fn (coco.py:320-351,
+    np.random seeded), COCO.encode_bitmap / decode_bitmap (:377-390), and pil_transforms.CropResize.crop_and_resize
+    (:105-138; bicubic for the image, nearest for the id map, to 512 x 512 as base.yaml's eval transforms do).
+    The fixture holds the four data files' bytes (inputs) and the reference's outputs."""
+    import hashlib
+    import io
+    from PIL import Image
+    from ldmseg.data.coco import COCO
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+    if "torchvision.transforms.functional" not in sys.modules:
+        mod("torchvision.transforms.functional")
+    from ldmseg.data.util.pil_transforms import CropResize
+    out = {}
+    names = ["000000012280", "000000084752"]
+    ex = os.path.join(REF, "data", "examples", "coco")
+    for k, name in enumerate(names):
+        jpg = open(os.path.join(ex, "rgb_images", name + ".jpg"), "rb").read()
+        png = open(os.path.join(ex, "panoptic_images", name + ".png"), "rb").read()
+        out[f"jpg_{k}"] = np.frombuffer(jpg, dtype=np.uint8)
+        out[f"png_{k}"] = np.frombuffer(png, dtype=np.uint8)
+        img = Image.open(io.BytesIO(jpg)).convert("RGB")
+        sem = np.array(Image.open(io.BytesIO(png)).convert("RGB"))
+        # coco.py:500-501: R + 256 G + 256^2 B.  (Under the reference's numpy 1.x the scalar factors promote the uint8 planes to
+        # uint16 / uint32; numpy 2 refuses the literal line with an OverflowError, so the planes are widened explicitly.)
+        ids_true = sem[:, :, 0].astype(np.int64) + 256 * sem[:, :, 1].astype(np.int64) + 65536 * sem[:, :, 2].astype(np.int64)
+        out[f"ids_{k}"] = ids_true.astype(np.int32)
+        dummy = types.SimpleNamespace(ignore_label=0, num_classes=128)
+        np.random.seed(100 + k)
+        remapped, mapping = COCO._remap_labels_fn(dummy, ids_true.copy(), max_val=128, keep_background_fixed=True)
+        out[f"remapped_{k}"] = remapped.astype(np.uint8)
+        out[f"mapping_{k}"] = np.array(sorted((int(a), int(b)) for a, b in mapping.items()), dtype=np.int64)
+        bits, ignore = COCO.encode_bitmap(dummy, torch.from_numpy(remapped.astype(np.int64)), n=7, fill_value=0.5)
+        out[f"bits_{k}"] = bits.numpy().astype(np.float16)                               # 0 / 0.5 / 1: exact in fp16
+        out[f"ignore_{k}"] = ignore.numpy()
+        out[f"decoded_{k}"] = COCO.decode_bitmap(dummy, 2.0 * bits - 1.0).numpy().astype(np.uint8)
+        cr = CropResize(512)
+        r_img = np.asarray(cr.crop_and_resize(img, 512, 512, mode="bicubic"))
+        r_ids = np.asarray(cr.crop_and_resize(Image.fromarray(remapped.astype(np.uint8)), 512, 512, mode="nearest"))
+        out[f"resized_sample_{k}"] = r_img[::8, ::8].copy()                              # every 8th pixel of the 512 x 512 image
+        out[f"resized_sha_{k}"] = np.frombuffer(hashlib.sha256(r_img.tobytes()).digest(), dtype=np.uint8)
+        out[f"resized_ids_{k}"] = r_ids
+        print(name, img.size, "segments", len(mapping), "void px", int(ignore.sum()))
+    np.savez_compressed(os.path.join(HERE, "real_coco.npz"), **out)
+    print("real_coco.npz ok", os.path.getsize(os.path.join(HERE, "real_coco.npz")), "bytes")
+
+
 def main():
     if not os.path.isdir(REF):
         print("reference not present; nothing to do")
@@ -237,8 +290,9 @@ def main():
     colormap_golden()
     try:
         bitcodec_golden()
+        real_coco_golden()
     except Exception as e:   # the dataset module drags in many optional deps
-        print('bitcodec golden skipped:', repr(e))
+        print('bitcodec / real-data golden skipped:', repr(e))
 
 
 if __name__ == "__main__":

@@ -187,3 +187,39 @@ def test_main_ldm_eval_entry_subprocess(tmp_path):
     assert "PQ" in r.stdout and "num_predictions" in r.stdout
     assert sorted(os.listdir(out_dir)) == ["000.png", "001.png", "predictions.json"]
     assert np.asarray(Image.open(out_dir / "001.png")).shape[:2] == (144, 100)
+
+
+def test_real_coco_pairs_through_bit_codec_and_eval_entry(golden, tmp_path):
+    """The reference's own example pairs on the GPU path: (1) the bit codec kernels on the REAL remapped
+    panoptic maps - bit-exact against what the reference's COCO.encode_bitmap / decode_bitmap produced (fixture), through
+    the affine 2x-1 the sampler applies; (2) tools/main_ldm_eval.py on the two non-square images (480 x 640 and 640 x 427 ->
+    PIL resize to 512 x 512 -> image VAE -> DDIM -> decode -> back to the original sizes) with the real panoptic PNGs as
+    ground truth: the prediction PNGs must come back at each image's own size and the PQ table must be produced."""
+    import io
+    from PIL import Image
+    from ldmseg_amd.data.bitcodec import decode_bitmap, encode_bitmap
+    g = golden("real_coco.npz")
+    for k in range(2):
+        remapped = torch.from_numpy(g[f"remapped_{k}"].astype(np.int64)).cuda()
+        bits, ign = encode_bitmap(remapped, n=7, fill_value=0.5, ignore_label=0)
+        assert torch.equal(bits.cpu(), torch.from_numpy(g[f"bits_{k}"].astype(np.float32)))
+        assert torch.equal(ign.cpu(), torch.from_numpy(g[f"ignore_{k}"]))
+        net_in, _ = encode_bitmap(remapped, n=7, fill_value=0.5, ignore_label=0, affine=(2.0, -1.0))
+        assert torch.equal(net_in, 2.0 * bits - 1.0)
+        assert torch.equal(decode_bitmap(net_in).cpu(), torch.from_numpy(g[f"decoded_{k}"].astype(np.int64)))
+    img_dir, gt_dir, out_dir = tmp_path / "rgb", tmp_path / "pan", tmp_path / "out"
+    img_dir.mkdir(); gt_dir.mkdir()
+    names = ["000000012280", "000000084752"]
+    for k, n in enumerate(names):
+        (img_dir / f"{n}.jpg").write_bytes(g[f"jpg_{k}"].tobytes())
+        (gt_dir / f"{n}.png").write_bytes(g[f"png_{k}"].tobytes())
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "latent-diffusion-segmentation_amd")]))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "main_ldm_eval.py"), "--images", str(img_dir), "--panoptic", str(gt_dir),
+                        "--size", "512", "--steps", "3", "--batch", "2", "--dtype", "bf16", "--out", str(out_dir)],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "PQ" in r.stdout and "num_predictions" in r.stdout
+    assert sorted(os.listdir(out_dir)) == [names[0] + ".png", names[1] + ".png", "predictions.json"]
+    for k, n in enumerate(names):
+        w, h = Image.open(io.BytesIO(g[f"jpg_{k}"].tobytes())).size
+        assert np.asarray(Image.open(out_dir / f"{n}.png")).shape[:2] == (h, w)

@@ -101,3 +101,37 @@ def test_val_transforms_match_pil(tmp_path):
     ids = Image.fromarray(g.randint(0, 200, size=(10, 12)).astype(np.uint8))
     small = T.ids_to_tensor(T.crop_resize(ids, (5, 6), "nearest"))
     assert small.dtype == torch.int64 and small.shape == (5, 6)
+
+
+def test_real_coco_pairs_host_side(golden):
+    """Two of the reference's own example pairs (tests/golden/real_coco.npz: the jpg / png bytes + what the reference's
+    functions make of them, tests/golden/make_golden.py::real_coco_golden): the host side of the I/O rows - PNG colours ->
+    segment ids (evaluator's rgb2id = coco.py:500-501), the oracle bit codec on the REAL remapped id maps, and the PIL
+    resize to 512 x 512 (CropResize: bicubic for the image, nearest for ids) on a portrait and a landscape image."""
+    import hashlib
+    import io
+    from PIL import Image
+    from ldmseg_amd.data.transforms import crop_resize
+    from ldmseg_amd.evaluations import rgb2id
+    g = golden("real_coco.npz")
+    sizes = []
+    for k in range(2):
+        img = Image.open(io.BytesIO(g[f"jpg_{k}"].tobytes())).convert("RGB")
+        sem = np.array(Image.open(io.BytesIO(g[f"png_{k}"].tobytes())).convert("RGB"))
+        sizes.append(img.size)
+        ids = rgb2id(sem)
+        assert np.array_equal(ids, g[f"ids_{k}"])
+        assert ids.shape == (img.size[1], img.size[0]) and len(np.unique(ids)) >= 10       # real scenes: 12 / 19 segments + void
+        # the reference's random relabelling is a bijection of the segments onto 1..127 with void fixed at 0
+        remapped, mapping = g[f"remapped_{k}"], dict(g[f"mapping_{k}"].tolist())
+        assert set(np.unique(ids)) - {0} == set(mapping) and len(set(mapping.values())) == len(mapping)
+        assert np.array_equal(np.vectorize(lambda v: mapping.get(int(v), 0))(ids), remapped)
+        bits, ign = o_bits.encode_bitmap(remapped.astype(np.int64))
+        assert np.array_equal(bits, g[f"bits_{k}"].astype(np.float32)) and np.array_equal(ign, g[f"ignore_{k}"])
+        assert np.array_equal(o_bits.decode_bitmap(2 * bits - 1), g[f"decoded_{k}"]) and np.array_equal(g[f"decoded_{k}"], remapped)
+        r_img = np.asarray(crop_resize(img, (512, 512), "bicubic"))
+        assert np.array_equal(r_img[::8, ::8], g[f"resized_sample_{k}"])
+        assert hashlib.sha256(r_img.tobytes()).digest() == g[f"resized_sha_{k}"].tobytes()
+        r_ids = np.asarray(crop_resize(Image.fromarray(remapped), (512, 512), "nearest"))
+        assert np.array_equal(r_ids, g[f"resized_ids_{k}"])
+    assert sizes == [(480, 640), (640, 427)]                      # (width, height): one portrait, one landscape
