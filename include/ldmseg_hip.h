@@ -274,7 +274,11 @@ int ldmseg_profile_dump(const char* path);
  * rule (channel-major on large maps with many input channels), 0 = (tap, channel) everywhere, 1 = (channel tile, tap,
  * channel) wherever the layer holds that packing; key 10 = cooperative GroupNorm hand-off: 1 = every workgroup computes
  * its partners' statistics itself instead of waiting for them (the path a workgroup takes when its partners are not
- * co-resident; results are bit-identical), 0 = shipped; key 11 = bound of the partner poll in microseconds (default 100). */
+ * co-resident; results are bit-identical), 0 = shipped; key 11 = bound of the partner poll in microseconds (default 100);
+ * key 12 = row-local fusion of the 320-channel transformer feed-forward (bit 0: LayerNorm_3 -> GEGLU -> ff.net.2, bit 1: +
+ * proj_out; default 3, 0 = the unfused launches); key 13 bit 8 = no start-chunk rotation in that kernel; key 14 = step tail
+ * (bit 0: dedicated conv_out kernel in bf16, bit 1: the sampling loop's scheduler step / self-condition / next-input pack in
+ * its epilogue; default 3). */
 int ldmseg_debug_set(int key, int value);
 /* current value of a knob (key 1); key -1 = the shipped default of key 1.  Tests restore through this, never a literal.
  * key 10 = number of cooperative-GroupNorm workgroups that took the self-computing path in ldmseg_op_* launches so far. */

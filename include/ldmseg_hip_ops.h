@@ -75,6 +75,14 @@ int ldmseg_op_ln_linear(const float* x, const float* gamma, const float* beta, c
 int ldmseg_op_transformer_ff(const float* h, const float* x, const float* gamma, const float* beta, const float* w1, const float* b1,
                              const float* w2, const float* b2, const float* wp, const float* bp, int M, int C, float eps, int dtype,
                              int mode, float* out, int time_iters, float* us_per_call, void* stream);
+/* The step-tail kernel (tail.hip, bf16): eps = conv_out(x) (3x3, 320 -> 4, /root/reference/ldmseg/models/unet.py:433-436) and,
+ * with ddim != 0, DDIMNoiseScheduler.step (ddim_scheduler.py:231-267) on `latents` in place (last: pred_original_sample), the
+ * inpainting paste, the self-condition write (trainers_ldm_cond.py:1151-1159) and the next step's packed input
+ * [latents | rgb | cond | 0] as fp32 [B, H*W, 64].  coef4 is a HOST array; eps_out / cond / known / xin_out may be NULL. */
+int ldmseg_op_conv_out_tail(const float* x, const float* w, const float* bias, int B, int H, int W, float* eps_out, int ddim, int last,
+                            const float* coef4, int pred_type, int clip, float clip_range, float* latents, float* cond,
+                            const float* rgb, const uint8_t* known, const float* z0, const float* noise, float sa, float sb,
+                            float* xin_out, void* stream);
 /* Kernel timing for tuning (tools/kbench.py): the same launches repeated `iters` times back to back on `stream` between
  * two HIP events; *us_per_launch = average microseconds (igemm: including the split-K finish kernel if the plan has one). */
 int ldmseg_bench_igemm(const float* x, const float* x2, const float* w, const float* bias, const float* resid,

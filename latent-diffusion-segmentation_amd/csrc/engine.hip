@@ -465,6 +465,10 @@ struct ldmseg_unet {
   int temb_cap = 0;                    // steps the buffer holds
   const float* temb_override = nullptr;   // non-null while the loop runs a forward: this step's row (broadcast over the batch)
   void* gn_sync = nullptr;
+  // fused step tail (tail.hip): the sampling loop parks the scheduler step here before a forward; the forward's conv_out
+  // launch carries it out (tail_done) and leaves the next forward's packed input in place (xin_ready)
+  const StepTail* tail_req = nullptr;
+  bool tail_done = false, xin_ready = false;
 
   ~ldmseg_unet() {
     arena.release();
@@ -792,7 +796,9 @@ int unet_forward_impl(ldmseg_unet* u, const float* a, int Ca, const float* b, in
 
   // --- conv_in on the channel-concatenated fp32 NCHW input ---
   Act xin = ex.new_act(bke(dt), L, L, true);
-  {
+  if (!dry && u->xin_ready) {
+    u->xin_ready = false;          // the previous step's tail already wrote [latents | rgb | cond] here (tail.hip)
+  } else {
     ProfScope ps(4, s, 0, 0, dry);
     if (!dry) TRY(ex.ws_ok());
     if (!dry) TRY(launch_pack_concat3(a, Ca, b, Cb, c, Cc, xin.p, B, L * L, bke(dt), dt, s));
@@ -848,11 +854,32 @@ int unet_forward_impl(ldmseg_unet* u, const float* a, int Ca, const float* b, in
     const size_t m = ws->mark();
     Act n;
     TRY(ex.groupnorm(u->norm_out, h, nullptr, 1e-5f, 1, &n));
-    IgemmParams p;
-    p.src0 = n.p; p.C0 = n.C; p.B = B; p.Hi = p.Ho = L; p.Wi = p.Wo = L;
-    p.taps = 9; p.M = B * L * L; p.N = u->conv_out.N; p.n_valid = 4;
-    p.W = u->conv_out.w; p.bias = u->conv_out.bias; p.out = out; p.epi = EPI_NCHW_F32;
-    TRY(ex.igemm(p));
+    if (conv_out_tail_ok(n.C, L, L, dt)) {
+      // bf16: conv_out as a halo-resident stencil and - inside ldmseg_sample_loop - the rest of the step in its epilogue
+      StepTail t;
+      if (u->tail_req && step_tail_fused() && !dry) {
+        t = *u->tail_req;
+        t.xin_next = t.last ? nullptr : xin.p;
+        t.eps_out = nullptr;
+      } else {
+        t.eps_out = out;
+      }
+      t.x = n.p; t.w = u->conv_out.w; t.bias = u->conv_out.bias; t.zeros = igemm_zero_page();
+      t.B = B; t.H = L; t.W = L;
+      ProfScope ps(0, s, 2.0 * B * L * L * 4 * 9 * n.C, (double)B * L * L * n.C * esize(dt), dry, "M=" + std::to_string(B * L * L) + " conv_out_tail ddim=" + std::to_string(t.ddim));
+      if (!dry) {
+        TRY(ex.ws_ok());
+        const int r = launch_conv_out_tail(t, s);
+        if (r) return fail(r == -2 ? LDMSEG_E_SHAPE : LDMSEG_E_HIP, "launch_conv_out_tail failed");
+        if (t.ddim) { u->tail_done = true; u->xin_ready = t.xin_next != nullptr; }
+      }
+    } else {
+      IgemmParams p;
+      p.src0 = n.p; p.C0 = n.C; p.B = B; p.Hi = p.Ho = L; p.Wi = p.Wo = L;
+      p.taps = 9; p.M = B * L * L; p.N = u->conv_out.N; p.n_valid = 4;
+      p.W = u->conv_out.w; p.bias = u->conv_out.bias; p.out = out; p.epi = EPI_NCHW_F32;
+      TRY(ex.igemm(p));
+    }
     ws->reset(m);
   }
   return 0;
@@ -1589,23 +1616,33 @@ int ldmseg_sample_loop(ldmseg_unet* h, const ldmseg_sample_cfg* cfg, float* late
   if (selfc) HIP_TRY(hipMemsetAsync(h->cond, 0, n * sizeof(float), s));   // condition = zeros_like(rgb_latents)
   const float* temb_rows = nullptr;
   TRY(loop_time_embeddings(h, cfg->timesteps, cfg->n_steps, s, &temb_rows));
-  struct Clear { ldmseg_unet* u; ~Clear() { u->temb_override = nullptr; } } clear{h};     // (also on the error returns below)
+  struct Clear { ldmseg_unet* u; ~Clear() { u->temb_override = nullptr; u->tail_req = nullptr; u->tail_done = false; u->xin_ready = false; } } clear{h};     // (also on the error returns below)
   for (int i = 0; i < cfg->n_steps; ++i) {
     h->temb_override = temb_rows + (size_t)i * h->temb_total;
-    TRY(unet_forward_checked(h, latents, 4, rgb_latents, 4, selfc ? h->cond : nullptr, selfc ? 4 : 0, nullptr, 1,
-                             cfg->timesteps[i], B, L, h->eps, s));
     const float* c = cfg->coef + 4 * i;
     DdimCoef dc{c[0], c[1], c[2], c[3], cfg->prediction_type, cfg->clip_sample, cfg->clip_sample_range, 0};
     const bool last = (i == cfg->n_steps - 1);
-    // condition <- pred_original_sample; latents <- prev_sample (last step: pred_original_sample)
-    if (!last) {
-      TRY(launch_ddim_step(h->eps, latents, latents, selfc ? h->cond : nullptr, n, dc, s));
-    } else {
-      TRY(launch_ddim_step(h->eps, latents, nullptr, latents, n, dc, s));
+    // the scheduler step of this iteration, offered to the forward's conv_out launch (bf16: tail.hip carries it out in its
+    // epilogue together with the inpainting paste, the self-condition write and the next step's input pack)
+    StepTail st;
+    st.ddim = 1; st.last = last ? 1 : 0; st.c = dc; st.latents = latents; st.cond = selfc ? h->cond : nullptr; st.rgb = rgb_latents;
+    if (inpaint) { st.known = cfg->known_dev; st.z0 = cfg->z0_dev; st.noise = cfg->noise_dev; st.sa = cfg->paste_coef[2 * i]; st.sb = cfg->paste_coef[2 * i + 1]; }
+    h->tail_req = &st;
+    h->tail_done = false;
+    TRY(unet_forward_checked(h, latents, 4, rgb_latents, 4, selfc ? h->cond : nullptr, selfc ? 4 : 0, nullptr, 1,
+                             cfg->timesteps[i], B, L, h->eps, s));
+    h->tail_req = nullptr;
+    if (!h->tail_done) {
+      // condition <- pred_original_sample; latents <- prev_sample (last step: pred_original_sample)
+      if (!last) {
+        TRY(launch_ddim_step(h->eps, latents, latents, selfc ? h->cond : nullptr, n, dc, s));
+      } else {
+        TRY(launch_ddim_step(h->eps, latents, nullptr, latents, n, dc, s));
+      }
+      if (inpaint)
+        TRY(launch_inpaint_paste(latents, cfg->z0_dev, cfg->noise_dev, cfg->known_dev, cfg->paste_coef[2 * i],
+                                 cfg->paste_coef[2 * i + 1], B, 4, L * L, s));
     }
-    if (inpaint)
-      TRY(launch_inpaint_paste(latents, cfg->z0_dev, cfg->noise_dev, cfg->known_dev, cfg->paste_coef[2 * i],
-                               cfg->paste_coef[2 * i + 1], B, 4, L * L, s));
     if (all_latents)
       HIP_TRY(hipMemcpyAsync(all_latents + (size_t)i * n, latents, n * sizeof(float), hipMemcpyDeviceToDevice, s));
   }
@@ -1683,7 +1720,8 @@ int ldmseg_debug_set(int key, int value) {
   if (key == 10) { gn_mode = value; groupnorm_set_coop(gn_mode, gn_poll); return 0; }
   if (key == 11) { gn_poll = value; groupnorm_set_coop(gn_mode, gn_poll); return 0; }
   if (key == 12) { mlp_fused_set_mode(value); ++g_plan_epoch; return 0; }
-  if (key == 13) { mlp_fused_set_dbg(value); return 0; }   // bit 8: no start-chunk rotation (bits 0-7: ablate builds)   // transformer feed-forward fusion: bit 0 MLP, bit 1 + proj_out
+  if (key == 13) { mlp_fused_set_dbg(value); return 0; }
+  if (key == 14) { step_tail_set_mode(value); return 0; }   // bit 0: dedicated conv_out kernel (bf16); bit 1: scheduler step in its epilogue   // bit 8: no start-chunk rotation (bits 0-7: ablate builds)   // transformer feed-forward fusion: bit 0 MLP, bit 1 + proj_out
   if (key == 6 || key == 7) { ops_bench_knob(key, value); return 0; }   // ldmseg_bench_igemm: 6 = weight copies rotated, 7 = folded-LN launch   // bits 0-7 ablation flags (LDMSEG_IGEMM_ABLATE builds), bits 8-12 tile policy
   static unsigned long long ts_ptr = 0;                // keys 3/4: low/high half of a device stamp buffer (ablate builds)
   if (key == 3) { ts_ptr = (ts_ptr & 0xffffffff00000000ull) | (unsigned)value; igemm_set_tsbuf((void*)(uintptr_t)ts_ptr); return 0; }
@@ -1696,6 +1734,7 @@ int ldmseg_debug_get(int key) {
   if (key == -1) return igemm_default_dbg();     // the shipped value of key 1
   if (key == 9) return igemm_get_cm_mode();
   if (key == 12) return mlp_fused_get_mode();
+  if (key == 14) return step_tail_get_mode();
   if (key == 10) { const long long n = gn_coop_fallbacks(nullptr); return n > 0x7fffffffll ? 0x7fffffff : (int)n; }   // ring regions (ldmseg_op_* launches)
   return 0;
 }

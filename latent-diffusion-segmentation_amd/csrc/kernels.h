@@ -218,6 +218,29 @@ int launch_repack_convt2(const float* w, void* out, int Ci, int Co, int dtype, h
 // DDIM step (ddim_scheduler.py:218-269), elementwise, bit-exact op order
 struct DdimCoef { float sqrt_a_t, sqrt_b_t, sqrt_a_prev, sqrt_b_prev; int pred_type; int clip; float clip_range; int use_clipped; };
 int launch_ddim_step(const float* eps, const float* x, float* prev, float* x0, size_t n, DdimCoef c, hipStream_t s);
+// The tail of a denoising step in one launch (tail.hip, bf16): conv_out on a halo-resident pixel tile and, when ddim != 0,
+// the scheduler update, inpainting paste, self-condition write and the next step's packed UNet input in its epilogue.
+struct StepTail {
+  const void* x = nullptr;        // [B, H*W, 320] SiLU(conv_norm_out(h)), bf16
+  const void* w = nullptr;        // conv_out weights packed [N][9*320] bf16 (rows 0..3 real)
+  const float* bias = nullptr;
+  const void* zeros = nullptr;
+  int B = 0, H = 0, W = 0;
+  float* eps_out = nullptr;       // [B,4,H,W] fp32: the model output (plain forward); may be null when ddim != 0
+  int ddim = 0, last = 0;
+  DdimCoef c{};
+  float* latents = nullptr;       // [B,4,H,W] fp32, updated in place (last step: pred_original_sample)
+  float* cond = nullptr;          // self-condition <- pred_original_sample, or null
+  const float* rgb = nullptr;
+  void* xin_next = nullptr;       // [B, H*W, 64] bf16: next step's packed input [latents | rgb | cond | 0], or null
+  const uint8_t* known = nullptr; const float* z0 = nullptr; const float* noise = nullptr;   // inpainting paste
+  float sa = 0.f, sb = 0.f;
+};
+bool conv_out_tail_ok(int C, int H, int W, int dtype);     // the shape has the kernel and debug key 14 bit 0 allows it
+bool step_tail_fused();                                      // key 14 bits 0 and 1: the sampling loop hands the scheduler step to it
+void step_tail_set_mode(int m);
+int step_tail_get_mode();
+int launch_conv_out_tail(const StepTail& t, hipStream_t s);
 // out = m ? (sa*z0 + sb*noise) : cur   (inpainting paste; m is u8 [B,1,L,L] broadcast on channels)
 int launch_inpaint_paste(float* cur, const float* z0, const float* noise, const uint8_t* known, float sa, float sb,
                          int B, int C, int HW, hipStream_t s);

@@ -630,6 +630,41 @@ int ldmseg_op_transformer_ff(const float* h, const float* x, const float* gamma,
   return 0;
 }
 
+// The step tail kernel (tail.hip, bf16): eps = conv2d(x, w, bias, padding=1) with 320 -> 4 channels on [B,320,H,W] and, when
+// ddim != 0, the scheduler update of `latents` (in place; last != 0: pred_original_sample), the inpainting paste, the
+// self-condition write and the next step's packed input (returned as fp32 [B, H*W, 64]).  eps_out / cond / xin_out / known
+// may be null.  coef4 = {sqrt_alpha_t, sqrt_beta_t, sqrt_alpha_prev, sqrt_beta_prev} (host).
+int ldmseg_op_conv_out_tail(const float* x, const float* w, const float* bias, int B, int H, int W, float* eps_out, int ddim, int last,
+                            const float* coef4, int pred_type, int clip, float clip_range, float* latents, float* cond,
+                            const float* rgb, const uint8_t* known, const float* z0, const float* noise, float sa, float sb,
+                            float* xin_out, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  Temp t;
+  if (!conv_out_tail_ok(320, H, W, DT_BF16)) return -2;
+  void* xp = t.get((size_t)B * H * W * 320 * 2);
+  if (launch_pack_nchw(x, xp, B, 320, H * W, 320, 1.f, 0.f, DT_BF16, s)) return -3;
+  void* wp = t.get((size_t)32 * 9 * 320 * 2);
+  if (launch_repack_conv(w, wp, 4, 320, 3, 3, 32, 320, DT_BF16, s)) return -3;
+  float* bp = (float*)t.get(32 * sizeof(float));
+  (void)hipMemsetAsync(bp, 0, 32 * sizeof(float), s);
+  if (bias) (void)hipMemcpyAsync(bp, bias, 4 * sizeof(float), hipMemcpyDeviceToDevice, s);
+  if (igemm_warm()) return -3;
+  StepTail st;
+  st.x = xp; st.w = wp; st.bias = bp; st.zeros = igemm_zero_page(); st.B = B; st.H = H; st.W = W; st.eps_out = eps_out;
+  void* xin = nullptr;
+  if (ddim) {
+    if (!coef4 || !latents) return -2;
+    st.ddim = 1; st.last = last;
+    st.c = DdimCoef{coef4[0], coef4[1], coef4[2], coef4[3], pred_type, clip, clip_range, 0};
+    st.latents = latents; st.cond = cond; st.rgb = rgb; st.known = known; st.z0 = z0; st.noise = noise; st.sa = sa; st.sb = sb;
+    if (xin_out) { xin = t.get((size_t)B * H * W * 64 * 2); (void)hipMemsetAsync(xin, 0xff, (size_t)B * H * W * 64 * 2, s); st.xin_next = xin; }
+  }
+  const int r = launch_conv_out_tail(st, s);
+  if (r) return r;
+  if (xin && !last) from_dev_dtype(xin, xin_out, (size_t)B * H * W * 64, DT_BF16, s);
+  return 0;
+}
+
 // the same attention on the fp8 (e4m3) operand path of the bf16 mode (attention_fp8.hip): head dim 40 or 80
 int ldmseg_op_attention_fp8(const float* qkv, int B, int N, int C, int heads, float* out, int time_iters, float* us_per_launch,
                             void* stream) {

@@ -5,6 +5,7 @@
 // FMA, and the in-source pragma does not survive inlining of the __f*_rn helpers).
 #include "common.h"
 #include "kernels.h"
+#include "sched_math.h"
 
 namespace ldmseg {
 namespace {
@@ -23,22 +24,9 @@ inline int ok() { return hipGetLastError() == hipSuccess ? 0 : -3; }
 __global__ void ddim_step_kernel(const float* eps_in, const float* x_in, float* prev, float* x0_out, size_t n, DdimCoef c) {
 #pragma clang fp contract(off)
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const float mo = eps_in[i], x = x_in[i];
-    float x0, pe;
-    if (c.pred_type == 0) {          // epsilon
-      x0 = __fdiv_rn(__fsub_rn(x, __fmul_rn(c.sqrt_b_t, mo)), c.sqrt_a_t);
-      pe = mo;
-    } else if (c.pred_type == 1) {   // sample
-      x0 = mo;
-      pe = __fdiv_rn(__fsub_rn(x, __fmul_rn(c.sqrt_a_t, x0)), c.sqrt_b_t);
-    } else {                         // v_prediction
-      x0 = __fsub_rn(__fmul_rn(c.sqrt_a_t, x), __fmul_rn(c.sqrt_b_t, mo));
-      pe = __fadd_rn(__fmul_rn(c.sqrt_a_t, mo), __fmul_rn(c.sqrt_b_t, x));
-    }
-    if (c.clip) x0 = fminf(fmaxf(x0, -c.clip_range), c.clip_range);
-    if (c.use_clipped) pe = __fdiv_rn(__fsub_rn(x, __fmul_rn(c.sqrt_a_t, x0)), c.sqrt_b_t);
-    const float dir = __fmul_rn(c.sqrt_b_prev, pe);
-    if (prev) prev[i] = __fadd_rn(__fmul_rn(c.sqrt_a_prev, x0), dir);
+    float pv, x0;
+    ddim_update(eps_in[i], x_in[i], c, pv, x0);
+    if (prev) prev[i] = pv;
     if (x0_out) x0_out[i] = x0;
   }
 }

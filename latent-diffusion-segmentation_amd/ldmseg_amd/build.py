@@ -13,9 +13,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.normpath(os.path.join(HERE, "..", "csrc"))
 INCLUDE = os.path.normpath(os.path.join(HERE, "..", "..", "include"))
 LIB_PATH = os.path.join(HERE, "libldmseg_hip.so")
-SOURCES = ["igemm.hip", "tfuse.hip", "norm.hip", "attention.hip", "attention3.hip", "attention_fp8.hip", "misc.hip", "postproc.hip", "sched.hip", "engine.hip", "ops_api.hip"]
+SOURCES = ["igemm.hip", "tfuse.hip", "tail.hip", "norm.hip", "attention.hip", "attention3.hip", "attention_fp8.hip", "misc.hip", "postproc.hip", "sched.hip", "engine.hip", "ops_api.hip"]
 EXTRA_FLAGS = {
     "sched.hip": ["-ffp-contract=off"],                       # bit-exact scheduler arithmetic
+    "tail.hip": ["-ffp-contract=off"],                        # the fused step tail carries the same arithmetic
     "attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"],    # scores feed VALU softmax: keep MFMA results in VGPRs
     "attention3.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"],
     "attention_fp8.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-fno-honor-nans"],
@@ -54,7 +55,7 @@ def build_library(force=False, verbose=False):
     hipcc = _hipcc()
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, h) for h in ("common.h", "kernels.h", "igemm_tuned.inc")]
+    headers = [os.path.join(CSRC, h) for h in ("common.h", "kernels.h", "igemm_tuned.inc", "sched_math.h")]
     headers += [os.path.join(INCLUDE, h) for h in ("ldmseg_hip.h", "ldmseg_hip_ops.h")]
     jobs = []
     objs = []

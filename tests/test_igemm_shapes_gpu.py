@@ -200,6 +200,13 @@ def test_conv_out_shape_vs_oracle(L, dt, cfg):
     torch.cuda.synchronize()
     SEEN[(cfg, dt)].add(L.igemm_last_kernel().split(" ")[0])
     assert rel_err(out, ref) < (1e-3 if dt == BF16 else 1e-4)
+    if dt == BF16:          # the bf16 forward runs conv_out as the halo-resident stencil of tail.hip
+        out2 = torch.empty(ref.shape, device="cuda")
+        assert L.lib().ldmseg_op_conv_out_tail(P(dx), P(dw), P(db), B, lat, lat, P(out2), 0, 0, None, 0, 0, 1.0, None, None, None, None,
+                                               None, None, 0.0, 0.0, None, None) == 0
+        torch.cuda.synchronize()
+        assert rel_err(out2, ref) < 1e-3
+        SEEN[(cfg, dt)].add("conv_out_tail<bf16>")
 
 
 @pytest.mark.parametrize("cfg", CONFIGS, ids=CFG_IDS)

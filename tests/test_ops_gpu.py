@@ -843,3 +843,69 @@ def test_transformer_ff_fused_large_mean_rows(L):
     for m in (1, 3):
         o = _ff_run(L, case, M, Cc, m)[0]
         assert float((o.double() - ref.double()).norm() / ref.double().norm()) < 1.5e-2, m
+
+
+# ------------------------------------------------------------------ step tail (tail.hip): conv_out + DDIM + paste + pack
+@pytest.mark.parametrize("case", [
+    # B, H, W, pred_type, clip, last, self-condition, inpainting
+    (2, 16, 16, 0, 0, 0, 1, 0),
+    (1, 8, 32, 0, 0, 0, 1, 1),            # a single tile row; inpainting paste
+    (2, 32, 32, 2, 1, 0, 0, 0),           # v-prediction + clipping, 8-channel variant (no self-condition)
+    (2, 16, 32, 1, 0, 1, 1, 1),           # last step: latents <- pred_original_sample, then the paste
+    (8, 64, 64, 0, 0, 0, 1, 0),           # configs[1] size
+])
+def test_step_tail_kernel(L, case):
+    """conv_out as the halo-resident stencil (vs F.conv2d on the bf16-rounded operands) and, fused into its epilogue, the
+    scheduler step: latents / self-condition must equal ldmseg_ddim_step (+ ldmseg's paste arithmetic) on the SAME eps bit
+    for bit, and the packed next input must be bf16([latents | rgb | cond | 0]) exactly."""
+    B, H, W, pt, clip, last, selfc, inp = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, 320, H, W, generator=g)
+    w = torch.randn(4, 320, 3, 3, generator=g) / (320 * 9) ** 0.5
+    b = torch.randn(4, generator=g)
+    lat = torch.randn(B, 4, H, W, generator=g)
+    rgb = torch.randn(B, 4, H, W, generator=g)
+    z0 = torch.randn(B, 4, H, W, generator=g)
+    noise = torch.randn(B, 4, H, W, generator=g)
+    known = (torch.rand(B, 1, H, W, generator=g) < 0.5).to(torch.uint8)
+    coef = (C.c_float * 4)(0.41, 0.912, 0.53, 0.848)
+    sa, sb = 0.6, 0.8
+    lib = L.lib()
+    dx, dw, db = dev(x), dev(w), dev(b)
+    eps = torch.empty(B, 4, H, W, device="cuda")
+    assert lib.ldmseg_op_conv_out_tail(P(dx), P(dw), P(db), B, H, W, P(eps), 0, 0, None, 0, 0, 1.0, None, None, None, None, None, None,
+                                       0.0, 0.0, None, None) == 0
+    torch.cuda.synchronize()
+    ref = F.conv2d(bf16_round(x), bf16_round(w), b, padding=1)
+    assert rel_err(eps, ref) < 1e-3, case
+    # fused step
+    lat_f, cond_f = lat.cuda().clone(), torch.full((B, 4, H, W), 7.0, device="cuda")
+    drgb, dz0, dnoise, dknown = dev(rgb), dev(z0), dev(noise), known.cuda()
+    xin = torch.empty(B, H * W, 64, device="cuda")
+    eps2 = torch.empty_like(eps)
+    assert lib.ldmseg_op_conv_out_tail(P(dx), P(dw), P(db), B, H, W, P(eps2), 1, last, coef, pt, clip, 1.0, P(lat_f),
+                                       P(cond_f) if selfc else None, P(drgb), P(dknown) if inp else None, P(dz0), P(dnoise), sa, sb,
+                                       P(xin), None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(eps2, eps)
+    # the unfused sequence on the same eps
+    prev, x0 = torch.empty_like(eps), torch.empty_like(eps)
+    dlat = lat.cuda()
+    assert lib.ldmseg_ddim_step(P(eps), P(dlat), coef[0], coef[1], coef[2], coef[3], pt, clip, 1.0, 0, P(prev), P(x0), B * 4 * H * W, None) == 0
+    torch.cuda.synchronize()
+    want = (x0 if last else prev).clone()
+    if inp:
+        paste = (torch.tensor(sa) * z0.cuda()) + (torch.tensor(sb) * noise.cuda())      # fp32, each op rounded (torch eager)
+        want = torch.where(dknown.bool().expand_as(want), paste, want)
+    assert torch.equal(lat_f, want), case
+    if selfc and not last:
+        assert torch.equal(cond_f, x0)
+    elif selfc:
+        assert bool((cond_f == 7.0).all())          # last step: the self-condition is not written
+    if not last:
+        exp = torch.zeros(B, H * W, 64)
+        exp[:, :, 0:4] = want.cpu().reshape(B, 4, H * W).permute(0, 2, 1)
+        exp[:, :, 4:8] = rgb.reshape(B, 4, H * W).permute(0, 2, 1)
+        if selfc:
+            exp[:, :, 8:12] = x0.cpu().reshape(B, 4, H * W).permute(0, 2, 1)
+        assert torch.equal(xin.cpu(), bf16_round(exp)), case
