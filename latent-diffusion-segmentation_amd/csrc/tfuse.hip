@@ -41,7 +41,9 @@ constexpr int kLds = kXT + kHT + kRing;  // 163840 = the CU's whole LDS
 constexpr int kW1Tile = 128 * 128;       // bytes of one W1 K tile (128 packed GEGLU rows)
 constexpr int kW2Unit = kC * 128;        // bytes of a [320 rows][128 B] unit (W2 chunk, proj_out K tile)
 constexpr int kChunkBytes = kKT * kW1Tile + kW2Unit;   // 122880
-constexpr int kPUnit = (kC / 2) * 128;   // 20480: proj_out unit = [160 rows of one N half][128 B] (two consecutive 40 KB units would not fit the ring)
+constexpr int kW2A = 192 * 128, kW2B = 128 * 128;     // the W2 chunk as two units: output fragments 0..2 / 3..4 of every wave
+constexpr int kPUnit = 192 * 128;        // 24576: proj_out unit = [160 rows of one N half + 32 rows of padding][128 B] (two consecutive
+                                         // 40 KB units would not fit the ring; 24 KB keeps every unit a multiple of the loaders' 8 KB round)
 
 __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
   asm volatile(
@@ -57,6 +59,17 @@ __device__ __forceinline__ void glds16_sbase(unsigned voff, const void* sbase, u
       "s_mov_b32 m0, %2\n\t"
       "s_nop 3\n\t"   // (M0 write -> LDS-DMA: 1 wait state; SGPR base written by SALU -> VMEM: 5; see igemm.hip)
       "global_load_lds_dwordx4 %0, %1"
+      :
+      : "v"(voff), "s"(sbase), "s"(lds_dst)
+      : "memory");
+}
+// two consecutive pieces (2 KiB) from one base: the instruction's immediate offset moves the LDS address along with the global one
+__device__ __forceinline__ void glds16x2_sbase(unsigned voff, const void* sbase, unsigned lds_dst) {
+  asm volatile(
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 3\n\t"
+      "global_load_lds_dwordx4 %0, %1\n\t"
+      "global_load_lds_dwordx4 %0, %1 offset:1024"
       :
       : "v"(voff), "s"(sbase), "s"(lds_dst)
       : "memory");
@@ -85,6 +98,7 @@ struct MlpFusedParams {
   float eps;
   int rot_tiles;           // > 0: tiles per image; the workgroup starts its hidden-chunk sweep at a chunk derived from its tile index inside the image
   int dbg;                 // -DLDMSEG_TFUSE_ABLATE builds: phase-ablation flags (results are wrong when != 0)
+  int ldr_delay;           // tuning: loader waves sleep 64 * {0, 2, 4, 8}[ldr_delay] cycles after a barrier before they issue
 };
 #ifdef LDMSEG_TFUSE_ABLATE
 #define TFDBG(p, bit) ((LDMSEG_TFUSE_ABLATE) & (bit))     // compile-time mask: run-time flags cost registers (the 168-budget kernel spilled)
@@ -105,8 +119,9 @@ __global__ __launch_bounds__(768, 3) void mlp_fused_kernel(const MlpFusedParams 
   const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m0 = blockIdx.x * kBM;
   const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)smem);
-  // units of the weight stream, in consumption order: per chunk 5 x W1 tile (4 pieces per loader wave) + W2 (10); PROJ: 10 x 5
-  const int nunits = p.nchunks * 6 + (PROJ ? 2 * kKT : 0);
+  // units of the weight stream, in consumption order: per chunk W1 K tiles {0,1} (8 pieces per loader wave), {2,3} (8), {4} (4),
+  // W2 part A (6), W2 part B (4); PROJ: 10 x 6
+  const int nunits = p.nchunks * 5 + (PROJ ? 2 * kKT : 0);
   // Every workgroup consumes the same stream; started at the same chunk they would all ask the L2 for the same lines at the
   // same moment.  The sweep over the hidden chunks is a sum, so each tile starts it elsewhere (a function of the tile's index
   // INSIDE its image only: an image's result does not depend on its position in the batch).
@@ -133,56 +148,54 @@ __global__ __launch_bounds__(768, 3) void mlp_fused_kernel(const MlpFusedParams 
     // pointer increments instead of index arithmetic, and per step  wait(unit t+1 landed) -> barrier -> issue into the space
     // unit t just freed  (the issue runs in the shadow of the compute waves' next step).
     __builtin_amdgcn_s_setprio(3);
-    const int nchunk_units = p.nchunks * 6;
+    const int nchunk_units = p.nchunks * 5;
     const int chunk_pieces = p.nchunks * 30;                          // this wave's pieces of the chunk region (circular: rotation)
-    int left = chunk_pieces + (PROJ ? 2 * kKT * 5 : 0);               // pieces this wave still has to issue
+    int left = chunk_pieces + (PROJ ? 2 * kKT * 6 : 0);               // pieces this wave still has to issue
     int iss = 0;                                                      // issued so far
     const unsigned voff = (unsigned)lane * 16u;
-    const unsigned char* src = p.stream + ((size_t)start * 120 + lw) * 1024;
-    int to_wrap = chunk_pieces - start * 30;                          // pieces until the source wraps to chunk 0 / moves on to proj_out
-    bool in_chunks = true;
-    unsigned dst = (unsigned)lw * 1024u;                              // ring offset of the next piece
+    // Every unit is a multiple of 8 KiB, so the stream is a sequence of 8 KiB rounds in which wave lw owns the 2 KiB block
+    // (two pieces) at offset 2 KiB * lw: per block one 64-bit add, one ring-offset add + and, one M0 write and two DMA
+    // instructions (the first version spent ~22 scalar instructions and three taken branches per piece).
+    const unsigned char* src = p.stream + (size_t)start * kChunkBytes + (size_t)lw * 2048;
+    int to_wrap = (p.nchunks - start) * 15;                           // blocks until the source wraps to chunk 0 / moves on to proj_out
+    unsigned dst = (unsigned)lw * 2048u;                              // ring offset of the next block
     auto issue_n = [&](int n) __attribute__((always_inline)) {
-      for (int i = 0; i < n && left > 0; ++i) {
+      for (int i = 0; i < n && left > 0; i += 2) {
         if (!TFDBG(p, 1)) {
           const unsigned long long su = (unsigned long long)(uintptr_t)src;
           const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)su), hi = __builtin_amdgcn_readfirstlane((unsigned)(su >> 32));
-          glds16_sbase(voff, (const void*)(uintptr_t)(((unsigned long long)hi << 32) | lo),
-                       __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(kXT + kHT) + dst));
+          glds16x2_sbase(voff, (const void*)(uintptr_t)(((unsigned long long)hi << 32) | lo),
+                         __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(kXT + kHT) + dst));
         }
-        src += 4096;
-        dst = (dst + 4096u) & (unsigned)(kRing - 1);
-        ++iss;
-        --left;
+        src += 8192;
+        dst = (dst + 8192u) & (unsigned)(kRing - 1);
+        iss += 2;
+        left -= 2;
         if (--to_wrap == 0) {
-          if (in_chunks && iss < chunk_pieces) { src = p.stream + (size_t)lw * 1024; to_wrap = chunk_pieces - iss; }   // chunk 0 follows the last chunk
-          else { src = p.stream + ((size_t)p.nchunks * 120 + lw) * 1024; in_chunks = false; to_wrap = 0x7fffffff; }     // proj_out region
+          if (iss < chunk_pieces) { src = p.stream + (size_t)lw * 2048; to_wrap = start * 15; }                        // chunk 0 follows the last chunk
+          else { src = p.stream + (size_t)p.nchunks * kChunkBytes + (size_t)lw * 2048; to_wrap = 0x7fffffff; }         // proj_out region
         }
       }
     };
     issue_n(16);
     wait_pieces(iss);                       // the row tile has landed (its pieces were issued first)
     __syncthreads();                        // A: tile ready for the LayerNorm pass
-    int land = 4;                           // this wave's pieces through the unit that must have landed next (unit 0: a W1 tile)
+    int land = 8;                           // this wave's pieces through the unit that must have landed next (unit 0: two W1 tiles)
     wait_pieces(iss - land);
     __syncthreads();                        // B: tile normalised, unit 0 landed
-    int pos = 0;                            // position of unit t inside its chunk (5 = the W2 chunk)
+    int pos = 0;                            // position of unit t inside its chunk
     for (int t = 0; t < nunits; ++t) {
       if (PROJ && t == nchunk_units) asm volatile("s_barrier" ::: "memory");   // pairs with the barrier between the ff epilogue and proj_out's K loop
-      const int sh_t = (t < nchunk_units) ? (pos == 5 ? 10 : 4) : 5;
+      const int sh_t = (t < nchunk_units) ? ((0x46488 >> (4 * pos)) & 15) : 6;          // shares by position: 8, 8, 4, 6, 4
       if (t + 1 < nunits) {
-        land += (t + 1 < nchunk_units) ? (pos == 4 ? 10 : 4) : 5;   // share of unit t+1
-        const int n = iss - land;
-        if (n == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");           // (the steady state of the chunk loop: 8, 8, 8, 8, 2, 2)
-        else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else wait_pieces(n);
+        const int pn = pos == 4 ? 0 : pos + 1;
+        land += (t + 1 < nchunk_units) ? ((0x46488 >> (4 * pn)) & 15) : 6;              // share of unit t+1
+        wait_pieces(iss - land);            // (steady state of the chunk loop: 0, 4, 6, 6, 4 pieces may stay in flight)
       }
-      TFSTAMP_L(24 + (t - 30) * 3 + 0, t >= 30 && t < 36)
       asm volatile("s_barrier" ::: "memory");           // end of step t: unit t+1 has landed, unit t is free
-      TFSTAMP_L(24 + (t - 30) * 3 + 1, t >= 30 && t < 36)
+      if (p.ldr_delay == 1) __builtin_amdgcn_s_sleep(2);
       issue_n(sh_t);
-      TFSTAMP_L(24 + (t - 30) * 3 + 2, t >= 30 && t < 36)
-      pos = (pos == 5) ? 0 : pos + 1;
+      pos = (pos == 4) ? 0 : pos + 1;
     }
     return;
   }
@@ -252,6 +265,7 @@ __global__ __launch_bounds__(768, 3) void mlp_fused_kernel(const MlpFusedParams 
   unsigned uoff = 0;                        // ring offset of the current unit
   const unsigned char* xrow = XT + (wm * 64) * 128 + fr_row;
   const unsigned char* hrow = HT + (wm * 64) * 128 + fr_row;
+  constexpr unsigned RM = (unsigned)(kRing - 1);
   int c = start;
   for (int ci = 0; ci < p.nchunks; ++ci, c = (c + 1 == p.nchunks) ? 0 : c + 1) {
     f32x4 acc1[2][4];
@@ -262,87 +276,82 @@ __global__ __launch_bounds__(768, 3) void mlp_fused_kernel(const MlpFusedParams 
     if (ci == 5) { TFSTAMP(11) }
     const float* bp = p.bias1 + c * 128 + wn * 32 + lg * 4;
     const f32x4 bv = *(const f32x4*)bp, bg = *(const f32x4*)(bp + 16);
-#pragma unroll 1
-    for (int kt = 0; kt < kKT; ++kt) {
-      // W1 tile rows of this wave: [wn*32, wn*32 + 32) = one (value | gate) pair of 16-row blocks (a 2 KB block never wraps)
-      const unsigned char* w0 = RING + ((uoff + (unsigned)(wn * 32) * 128u) & (unsigned)(kRing - 1)) + fr_row;
-      const unsigned char* w1 = RING + ((uoff + (unsigned)(wn * 32 + 16) * 128u) & (unsigned)(kRing - 1)) + fr_row;
+    // one K tile of GEMM1; W1 tile rows of this wave: [wn*32, wn*32 + 32) = one (value | gate) pair of 16-row blocks (a 2 KB
+    // row block never wraps around the ring: units start on 8 KB boundaries)
+    auto gemm1_tile = [&](int kt, unsigned tile_off) __attribute__((always_inline)) {
+      const unsigned char* w0 = RING + ((uoff + tile_off + (unsigned)(wn * 32) * 128u) & RM) + fr_row;
+      const unsigned char* w1 = RING + ((uoff + tile_off + (unsigned)(wn * 32 + 16) * 128u) & RM) + fr_row;
       const unsigned char* xs = xrow + kt * (kBM * 128);
 #pragma unroll
       for (int kg = 0; kg < 2; ++kg) {
         const int co = kg ? fr_c1 : fr_c0;
         uint4 xf[4], wf[2];
-        if (!TFDBG(p, 16)) {
-          wf[0] = *(const uint4*)(w0 + co);
+        wf[0] = *(const uint4*)(w0 + co);
 #pragma unroll
-          for (int b = 0; b < 4; ++b) xf[b] = *(const uint4*)(xs + b * 2048 + co);
-          wf[1] = *(const uint4*)(w1 + co);
-        } else {
+        for (int b = 0; b < 4; ++b) xf[b] = *(const uint4*)(xs + b * 2048 + co);
+        wf[1] = *(const uint4*)(w1 + co);
 #pragma unroll
-          for (int b = 0; b < 4; ++b) xf[b] = make_uint4(lane, b, kt, 1);
-          wf[0] = wf[1] = make_uint4(lane, 3, kt, 7);
-        }
-        if (!TFDBG(p, 4)) {
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-          for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) mma_kgroup<bf16_t>(wf[a], xf[b], acc1[a][b]);
-        } else {
-#pragma unroll
-          for (int a = 0; a < 2; ++a) asm volatile("" ::"v"(wf[a].x), "v"(wf[a].w));
-#pragma unroll
-          for (int b = 0; b < 4; ++b) asm volatile("" ::"v"(xf[b].x), "v"(xf[b].w));
-        }
+          for (int b = 0; b < 4; ++b) mma_kgroup<bf16_t>(wf[a], xf[b], acc1[a][b]);
       }
-      if (kt == kKT - 1) {
-        // GEGLU on the finished chunk: value and gate of 16 hidden columns sit in the same lane.  The bf16 result is this
-        // chunk's X operand for ff.net.2: row m, hidden k = wn*16 + lg*4 + {0..3} -> 8 bytes of HT[m][k]
+    };
+    // Steps are TWO K tiles wide where the ring allows it: a barrier step costs ~0.4 us of loop / issue / barrier overhead
+    // whatever is in it (stamps: an empty step took as long), and one K tile is only 16 MFMAs per wave (0.12 us)
+    gemm1_tile(0, 0u);
+    gemm1_tile(1, (unsigned)kW1Tile);
+    __syncthreads();
+    uoff = (uoff + 2u * kW1Tile) & RM;
+    gemm1_tile(2, 0u);
+    gemm1_tile(3, (unsigned)kW1Tile);
+    __syncthreads();
+    uoff = (uoff + 2u * kW1Tile) & RM;
+    gemm1_tile(4, 0u);
+    // GEGLU on the finished chunk: value and gate of 16 hidden columns sit in the same lane.  The bf16 result is this
+    // chunk's X operand for ff.net.2: row m, hidden k = wn*16 + lg*4 + {0..3} -> 8 bytes of HT[m][k]
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          const f32x4 av = acc1[0][b] + bv, gv = acc1[1][b] + bg;
-          const f32x4 o = TFDBG(p, 2) ? av * gv : av * gelu_erf_bf16_f4(gv);
-          const int row = wm * 64 + b * 16 + lq;
-          const int ch = wn * 2 + (lg >> 1);
-          if (!TFDBG(p, 64)) *(uint2*)(HT + row * 128 + ((ch ^ (row & 7)) << 4) + (lg & 1) * 8) = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
-          else asm volatile("" ::"v"(o[0]), "v"(o[3]));
-        }
-      }
-      __syncthreads();
-      uoff = (uoff + kW1Tile) & (unsigned)(kRing - 1);
-      if (ci == 5) { TFSTAMP(16 + kt) }
+    for (int b = 0; b < 4; ++b) {
+      const f32x4 av = acc1[0][b] + bv, gv = acc1[1][b] + bg;
+      const f32x4 o = TFDBG(p, 2) ? av * gv : av * gelu_erf_bf16_f4(gv);
+      const int row = wm * 64 + b * 16 + lq;
+      const int ch = wn * 2 + (lg >> 1);
+      *(uint2*)(HT + row * 128 + ((ch ^ (row & 7)) << 4) + (lg & 1) * 8) = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
     }
+    __syncthreads();
+    uoff = (uoff + (unsigned)kW1Tile) & RM;
     if (ci == 5) { TFSTAMP(12) }
-    // ---- acc2 += H . W2_chunk^T : rows of W2 for this wave [wn*80, wn*80 + 80)
+    // ---- acc2 += H . W2_chunk^T in two units: A = this wave's output fragments 0..2 (rows wn*48 + a*16 of a 192-row unit),
+    //      B = fragments 3, 4 (rows wn*32 + (a-3)*16 of a 128-row unit): every wave works in both steps
 #pragma unroll
     for (int kg = 0; kg < 2; ++kg) {
       const int co = kg ? fr_c1 : fr_c0;
-      uint4 hf[4], wf[5];
-      if (!TFDBG(p, 32)) {
+      uint4 hf[4], wf[3];
 #pragma unroll
-        for (int b = 0; b < 4; ++b) hf[b] = *(const uint4*)(hrow + b * 2048 + co);
+      for (int b = 0; b < 4; ++b) hf[b] = *(const uint4*)(hrow + b * 2048 + co);
 #pragma unroll
-        for (int a = 0; a < 5; ++a)
-          wf[a] = *(const uint4*)(RING + ((uoff + (unsigned)(wn * 80 + a * 16) * 128u) & (unsigned)(kRing - 1)) + fr_row + co);
-      } else {
+      for (int a = 0; a < 3; ++a) wf[a] = *(const uint4*)(RING + ((uoff + (unsigned)(wn * 48 + a * 16) * 128u) & RM) + fr_row + co);
 #pragma unroll
-        for (int b = 0; b < 4; ++b) hf[b] = make_uint4(lane, b, 2, 1);
+      for (int a = 0; a < 3; ++a)
 #pragma unroll
-        for (int a = 0; a < 5; ++a) wf[a] = make_uint4(lane, a, 5, 7);
-      }
-      if (!TFDBG(p, 8)) {
-#pragma unroll
-        for (int a = 0; a < 5; ++a)
-#pragma unroll
-          for (int b = 0; b < 4; ++b) mma_kgroup<bf16_t>(wf[a], hf[b], acc2[a][b]);
-      } else {
-#pragma unroll
-        for (int a = 0; a < 5; ++a) asm volatile("" ::"v"(wf[a].x), "v"(wf[a].w));
-#pragma unroll
-        for (int b = 0; b < 4; ++b) asm volatile("" ::"v"(hf[b].x), "v"(hf[b].w));
-      }
+        for (int b = 0; b < 4; ++b) mma_kgroup<bf16_t>(wf[a], hf[b], acc2[a][b]);
     }
     __syncthreads();
-    uoff = (uoff + kW2Unit) & (unsigned)(kRing - 1);
+    uoff = (uoff + (unsigned)kW2A) & RM;
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg) {
+      const int co = kg ? fr_c1 : fr_c0;
+      uint4 hf[4], wf[2];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) hf[b] = *(const uint4*)(hrow + b * 2048 + co);
+#pragma unroll
+      for (int a = 0; a < 2; ++a) wf[a] = *(const uint4*)(RING + ((uoff + (unsigned)(wn * 32 + a * 16) * 128u) & RM) + fr_row + co);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) mma_kgroup<bf16_t>(wf[a], hf[b], acc2[3 + a][b]);
+    }
+    __syncthreads();
+    uoff = (uoff + (unsigned)kW2B) & RM;
     if (ci == 0) { TFSTAMP(4) }
     if (ci == 5) { TFSTAMP(13) }
     if (ci == 9) { TFSTAMP(5) }
@@ -529,13 +538,16 @@ __global__ __launch_bounds__(256) void tf_pack_stream_kernel(const bf16_t* __res
     } else {
       const int rem = o - kKT * kW1Tile;
       const int r = rem >> 7, pc = (rem & 127) >> 4, lc = pc ^ (r & 7);
-      src = w2 + (size_t)r * (4 * kC) + c * kHC + lc * 8;
+      // stream row r -> output column n: unit A holds every wave's fragments 0..2 (48 rows per wave), unit B fragments 3, 4
+      const int n = r < 192 ? (r / 48) * 80 + (r % 48) : ((r - 192) / 32) * 80 + 48 + ((r - 192) % 32);
+      src = w2 + (size_t)n * (4 * kC) + c * kHC + lc * 8;
     }
   } else {
     const int o = (int)(byte - chunk_end);
     const int kt = o / (2 * kPUnit), rem = o - kt * (2 * kPUnit);
     const int h = rem / kPUnit, rem2 = rem - h * kPUnit;
     const int r = rem2 >> 7, pc = (rem2 & 127) >> 4, lc = pc ^ (r & 7);
+    if (r >= kC / 2) { out[gid] = make_uint4(0u, 0u, 0u, 0u); return; }     // padding rows of the 24 KB unit
     src = wp + (size_t)(h * 160 + r) * kC + kt * 64 + lc * 8;
   }
   out[gid] = *(const uint4*)src;
@@ -551,7 +563,7 @@ bool mlp_fused_proj() { return (g_tfuse_mode & 2) != 0; }
 void mlp_fused_set_mode(int m) { g_tfuse_mode = m & 3; }
 void mlp_fused_set_dbg(int f) { g_tfuse_dbg = f; }
 int mlp_fused_get_mode() { return g_tfuse_mode; }
-size_t mlp_fused_stream_bytes(int C) { return C == kC ? (size_t)(4 * kC / kHC) * kChunkBytes + (size_t)kKT * kW2Unit : 0; }
+size_t mlp_fused_stream_bytes(int C) { return C == kC ? (size_t)(4 * kC / kHC) * kChunkBytes + (size_t)2 * kKT * kPUnit : 0; }
 
 int launch_pack_mlp_stream(const void* w1, const void* w2, const void* wp, void* out, int C, hipStream_t s) {
   if (C != kC || !w1 || !w2 || !wp || !out) return -2;
@@ -570,6 +582,7 @@ int launch_mlp_fused(const void* h, void* out, const void* x2, const void* strea
   p.stream = (const unsigned char*)stream; p.bias1 = bias1; p.bias2 = bias2; p.bias3 = bias3; p.zeros = zeros;
   p.M = M; p.nchunks = 4 * kC / kHC; p.eps = eps;
   p.dbg = g_tfuse_dbg & 0xff;
+  p.ldr_delay = (g_tfuse_dbg >> 16) & 3;
   // start-chunk rotation by the tile's index inside its image (whole tiles per image only; otherwise by nothing)
   p.rot_tiles = (!(g_tfuse_dbg & 256) && rows_per_image > 0 && rows_per_image % kBM == 0) ? rows_per_image / kBM : 0;
   const dim3 grid((M + kBM - 1) / kBM), block(768);

@@ -7,6 +7,6 @@ python __graft_entry__.py build | tail -1
 for m in "$@"; do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -DLDMSEG_TFUSE_ABLATE=$m -Iinclude -c $C/tfuse.hip -o /tmp/probe/tfuse_ablate.o \
     -Rpass-analysis=kernel-resource-usage 2>&1 | grep -A9 "mlp_fused_kernelILb1" | grep -E "VGPRs Spill" | sed "s/^.*remark:/mask $m:/"
-  hipcc --offload-arch=gfx950 -shared -fPIC -o scratch/lib_tf_ablate_$m.so /tmp/probe/tfuse_ablate.o $B/igemm.o $B/norm.o $B/attention.o $B/attention3.o $B/attention_fp8.o $B/misc.o $B/postproc.o $B/sched.o $B/engine.o $B/ops_api.o
+  hipcc --offload-arch=gfx950 -shared -fPIC -o scratch/lib_tf_ablate_$m.so /tmp/probe/tfuse_ablate.o $(ls $B/*.o | grep -v tfuse.o)
 done
 ls scratch/lib_tf_ablate_*.so

@@ -13,11 +13,14 @@ from ldmseg_amd import _lib  # noqa: E402
 from test_ops_gpu import _ff_case, dev, P  # noqa: E402
 
 L = _lib.lib()
+for kv in os.environ.get("KEYS", "").split(","):          # e.g. KEYS=13=0x10000 (debug key = value) before timing
+    if kv:
+        L.ldmseg_debug_set(int(kv.split("=")[0]), int(kv.split("=")[1], 0))
 for M in [int(a) for a in sys.argv[1:]] or [32768, 65536]:
     case = [dev(t) for t in _ff_case(M, 320, 1)]
     out = torch.empty(M, 320, device="cuda")
     fl = 2.0 * M * (8 * 320 * 320 + 4 * 320 * 320 + 320 * 320)
-    for mode in (0, 1, 3):
+    for mode in [int(m) for m in os.environ.get("MODES", "0,1,3").split(",")]:
         us = C.c_float(0)
         r = L.ldmseg_op_transformer_ff(*[P(t) for t in case], M, 320, 1e-5, 1, mode, P(out), 20, C.byref(us), None)
         assert r == 0, r
