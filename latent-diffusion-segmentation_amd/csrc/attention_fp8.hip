@@ -371,6 +371,7 @@ int run8(const void* qkv, void* kv8, void* out, int B, int N, int C, int heads, 
 // bytes of the fp8 K/V scratch launch_attention_fp8 needs (0 = head dim not supported by the fp8 path)
 size_t attention_fp8_scratch_bytes(int B, int N, int C, int heads) {
   const int d = C / heads;
+  if (const size_t mx = attention_mx_scratch_bytes(B, N, C, heads)) return mx;       // head dim 40, whole 128-key tiles: the scaled-MFMA path
   if (d == 40) return (size_t)2 * B * heads * N * A8Cfg<40>::DP;
   if (d == 80) return (size_t)2 * B * heads * N * A8Cfg<80>::DP;
   return 0;
@@ -379,6 +380,7 @@ size_t attention_fp8_scratch_bytes(int B, int N, int C, int heads) {
 // qkv bf16 [B, N, 3C] -> out bf16 [B, N, C] with fp8 (e4m3) Q/K/V/P operands; kv8 = scratch of attention_fp8_scratch_bytes
 int launch_attention_fp8(const void* qkv, void* kv8, void* out, int B, int N, int C, int heads, hipStream_t s) {
   const int d = C / heads;
+  if (attention_mx_ok(N, C, heads)) return launch_attention_mx(qkv, kv8, out, B, N, C, heads, s);   // 2x-rate block-scaled MFMAs (attention_mx.hip)
   if (d == 40) return run8<40, 2, 4, 3>(qkv, kv8, out, B, N, C, heads, s);
   if (d == 80) return run8<80, 2, 2, 3>(qkv, kv8, out, B, N, C, heads, s);
   return -2;

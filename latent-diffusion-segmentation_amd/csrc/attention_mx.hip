@@ -1,0 +1,346 @@
+// fp8 self-attention on the 2x-rate block-scaled MFMAs of gfx950 (v_mfma_scale_f32_32x32x64_f8f6f4 for S^T = K Q^T,
+// v_mfma_scale_f32_16x16x128_f8f6f4 for O^T += V^T P^T; e4m3 operands, unit E8M0 scales) - the "fp8 MFMA attention path" of
+// BASELINE configs[4] (1024x1024 images: 16384 tokens at head dim 40).  attention_fp8.hip runs the same arithmetic on
+// v_mfma_f32_16x16x32_fp8_fp8, which has the bf16 rate; here a 128-key tile of 32 queries costs 4 x 64 + 6 x 32 = 448 MFMA
+// cycles instead of 896.  Operand layouts were determined on the hardware (tools/ubench/mx_probe.hip): a lane holds 32
+// CONSECUTIVE k of one row - row = lane & 31, k = 32 (lane >> 5) + byte for 32x32x64; row = lane & 15, k = 32 (lane >> 4) +
+// byte for 16x16x128; C/D as for the unscaled shapes.
+//
+//  * QK^T: A = K (32 keys x 64 bytes: d = 40 values, two ones columns for the folded maximum, zeros), B = Q (32 queries).
+//    The result gives lane (q = lane & 31, h = lane >> 5) sixteen keys of ONE query per MFMA: the softmax of a query is
+//    in-lane work plus one permlane32 exchange.
+//  * The lane's 64 probabilities of a 128-key tile (four MFMAs) are exactly the 2 x 32 contraction bytes two PV operands
+//    need, once v_permlane16_swap has exchanged half of them between lanes l and l ^ 16: eight swaps per tile, no LDS.
+//    Which key ends up in which contraction slot is a fixed permutation - the pre-pass writes V^T in that order.
+//  * Pre-pass (kv_to_mx_kernel): K and V of the fused bf16 qkv tensor become per-(head, 128-key tile) LDS images,
+//    K [128 keys][64 B] and V^T [48 rows][128 slots], XOR-swizzled for conflict-free ds_read_b128 (searched over the
+//    hardware's 16-lane read groups), so a tile is 14 linear 1 KiB LDS-DMA pieces.
+// Folded maximum (two e4m3-exact parts in columns 40, 41 of Q against the ones columns of K), p shifted to the top of the
+// e4m3 range, row sum through a ones row of V^T: as in attention_fp8.hip.
+#include <type_traits>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace ldmseg {
+namespace {
+
+constexpr int kD = 40;
+constexpr int kTile = 128;                 // keys per tile
+constexpr int kKB = kTile * 64;            // 8192: K image of a tile
+constexpr int kVB = 48 * kTile;            // 6144: V^T image of a tile
+constexpr int kStage = kKB + kVB;          // 14336
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float clamp448m(float x) { return fminf(fmaxf(x, -448.f), 448.f); }
+__device__ __forceinline__ uint32_t pack_fp8x4m(float a, float b, float c, float d) {
+  int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+  return (uint32_t)w;
+}
+__device__ __forceinline__ float fp8_to_f32m(uint32_t byte) { return __builtin_amdgcn_cvt_f32_fp8((int)byte, 0); }
+__device__ __forceinline__ void glds16m(const void* gsrc, unsigned lds_dst) {
+  asm volatile(
+      "s_mov_b32 m0, %1\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %0, off"
+      :
+      : "v"(gsrc), "s"(lds_dst)
+      : "memory");
+}
+
+// contraction slot s = 32 g + j of a 128-key tile -> key (what lane (q, h) of the QK^T result holds after the permlane swap)
+__host__ __device__ constexpr int slot_key(int s) {
+  const int g = s >> 5, j = s & 31;
+  return 32 * (2 * (g & 1) + (j >> 4)) + (j & 3) + 8 * ((j & 15) >> 2) + 4 * (g >> 1);
+}
+
+// ---- pre-pass: one workgroup per (tile, head, image): K rows -> [128][64 B] image, V -> V^T [48][128 slots] image ----
+__global__ __launch_bounds__(256) void kv_to_mx_kernel(const bf16_t* __restrict__ qkv, unsigned char* __restrict__ k8,
+                                                       unsigned char* __restrict__ v8, int N, int C, int heads) {
+  __shared__ unsigned char vs[kTile][48];                  // fp8 V of the tile, [key][d]
+  const int T = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int tid = threadIdx.x;
+  const size_t bh = (size_t)b * heads + h;
+  const int ntiles = N / kTile;
+  // K: thread -> (key, 16-byte granule c of the 64-byte row)
+  for (int i = tid; i < kTile * 4; i += 256) {
+    const int key = i >> 2, c = i & 3;
+    const bf16_t* src = qkv + ((size_t)b * N + (size_t)T * kTile + key) * 3 * C + C + (size_t)h * kD + c * 16;
+    float f[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int d = c * 16 + e;
+      f[e] = d < kD ? clamp448m(bf16_to_f32(src[e])) : ((d == kD || d == kD + 1) ? 1.0f : 0.f);
+    }
+    const uint4 o = make_uint4(pack_fp8x4m(f[0], f[1], f[2], f[3]), pack_fp8x4m(f[4], f[5], f[6], f[7]),
+                               pack_fp8x4m(f[8], f[9], f[10], f[11]), pack_fp8x4m(f[12], f[13], f[14], f[15]));
+    *(uint4*)(k8 + (bh * ntiles + T) * kKB + key * 64 + ((c ^ ((key >> 2) & 3)) << 4)) = o;
+  }
+  // V: stage the tile as fp8 [key][d] ...
+  for (int i = tid; i < kTile * 3; i += 256) {
+    const int key = i / 3, c = i - key * 3;
+    const bf16_t* src = qkv + ((size_t)b * N + (size_t)T * kTile + key) * 3 * C + 2 * C + (size_t)h * kD + c * 16;
+    float f[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int d = c * 16 + e;
+      f[e] = d < kD ? clamp448m(bf16_to_f32(src[e])) : (d == kD ? 1.0f : 0.f);          // row 40 of V^T = ones: the row sum
+    }
+    *(uint4*)(&vs[key][c * 16]) = make_uint4(pack_fp8x4m(f[0], f[1], f[2], f[3]), pack_fp8x4m(f[4], f[5], f[6], f[7]),
+                                             pack_fp8x4m(f[8], f[9], f[10], f[11]), pack_fp8x4m(f[12], f[13], f[14], f[15]));
+  }
+  __syncthreads();
+  // ... and write V^T: thread -> (row d, physical granule cp): 16 contraction slots of one row
+  for (int i = tid; i < 48 * 8; i += 256) {
+    const int d = i >> 3, cp = i & 7;
+    const int c = cp ^ (((d & 15) >> 1) & 5);
+    uint32_t w[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      uint32_t v = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v |= (uint32_t)vs[slot_key(c * 16 + q * 4 + e)][d] << (8 * e);
+      w[q] = v;
+    }
+    *(uint4*)(v8 + (bh * ntiles + T) * kVB + d * 128 + cp * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+}
+
+template <int NST>
+__global__ __launch_bounds__(256, 3) void attn_mx_kernel(const bf16_t* __restrict__ qkv, const unsigned char* __restrict__ k8,
+                                                         const unsigned char* __restrict__ v8, bf16_t* __restrict__ out, int N, int C,
+                                                         int heads, float scale_log2e) {
+  constexpr float PSHIFT = 7.0f, THR = PSHIFT + 1.25f;     // (see attention_fp8.hip: p uses the top of the e4m3 range)
+  constexpr int UNIT = 0x7f7f7f7f;                          // E8M0 scale 2^0 for every 32-element block
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ql = lane & 31, hh = lane >> 5;                 // QK^T result: query column, key half
+  const int ntiles = N / kTile;
+  const int nqb = N / 128;                                  // 128 queries per workgroup (32 per wave)
+  int wg;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int qb = wg % nqb, bh = wg / nqb;
+  const int h = bh % heads, b = bh / heads;
+  const size_t ld = (size_t)3 * C;
+  const unsigned char* kbase = k8 + (size_t)bh * ntiles * kKB;
+  const unsigned char* vbase = v8 + (size_t)bh * ntiles * kVB;
+  const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)smem);
+
+  // ---- DMA stream: a tile is 8 K pieces + 6 V^T pieces of 1 KiB; wave w issues pieces w, w+4, w+8 (, w+12)
+  const int my_cnt = wave < 2 ? 4 : 3;
+  auto issue_tile = [&](int t, int stage) __attribute__((always_inline)) {
+    const unsigned char* kt = kbase + (size_t)t * kKB + lane * 16;
+    const unsigned char* vt = vbase + (size_t)t * kVB + lane * 16;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + stage * kStage);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int p = wave + 4 * j;
+      if (p < 8) glds16m(kt + p * 1024, dst + p * 1024);
+      else if (p < 14) glds16m(vt + (p - 8) * 1024, dst + p * 1024);
+    }
+  };
+  auto wait_tiles_ahead = [&](int ahead) __attribute__((always_inline)) {
+    if (ahead == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (my_cnt == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  };
+#pragma unroll
+  for (int j = 0; j < NST - 1; ++j)
+    if (j < ntiles) issue_tile(j, j);
+
+  // ---- Q operand (B of the 32x32x64 product): lane (q = ql, half hh) holds bytes 32 hh .. 32 hh + 31 of its row: d^-1/2 log2 e
+  // scaled e4m3; columns 40, 41 (the folded maximum) start at zero and live in bytes 8, 9 of the hh = 1 lanes
+  const int q_row = qb * 128 + wave * 32 + ql;
+  v8i qf;
+  {
+    const bf16_t* qp = qkv + ((size_t)b * N + q_row) * ld + (size_t)h * kD;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {                            // two 16-byte fp8 granules = 2 x 16 values
+      float f[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) f[e] = 0.f;
+      const int d0 = 32 * hh + 16 * c;
+      if (d0 < kD) {
+        float t[8];
+        Chunk<bf16_t>::unpack(*(const uint4*)(qp + d0), t);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = clamp448m(t[e] * scale_log2e);
+        if (d0 + 8 < kD) {
+          Chunk<bf16_t>::unpack(*(const uint4*)(qp + d0 + 8), t);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) f[8 + e] = clamp448m(t[e] * scale_log2e);
+        }
+      }
+#pragma unroll
+      for (int w = 0; w < 4; ++w) qf[c * 4 + w] = (int)pack_fp8x4m(f[4 * w], f[4 * w + 1], f[4 * w + 2], f[4 * w + 3]);
+    }
+  }
+
+  // fragment read offsets: K row = 32 kb + ql, granules 2 hh, 2 hh + 1 XOR ((ql >> 2) & 3); V^T row = 16 db + (lane & 15),
+  // granules 2 g, 2 g + 1 XOR (((lane & 15) >> 1) & 5)
+  const int ksw = (ql >> 2) & 3;
+  const int koff0 = ql * 64 + (((2 * hh) ^ ksw) << 4), koff1 = ql * 64 + (((2 * hh + 1) ^ ksw) << 4);
+  const int vr = lane & 15, vg = lane >> 4, vsw = (vr >> 1) & 5;
+  const int voff0 = kKB + vr * 128 + (((2 * vg) ^ vsw) << 4), voff1 = kKB + vr * 128 + (((2 * vg + 1) ^ vsw) << 4);
+
+  f32x4 o[2][3];                                             // O^T: [query block of 16][d block of 16]
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int d = 0; d < 3; ++d) o[a][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float mrow = 0.f;
+
+  wait_tiles_ahead((NST > 2 && ntiles > 1) ? 1 : 0);
+  __syncthreads();
+
+  auto tile = [&](int t, auto stage_c) __attribute__((always_inline)) {
+    constexpr int ST = decltype(stage_c)::value;
+    if (t + NST - 1 < ntiles) issue_tile(t + NST - 1, (ST + NST - 1) % NST);
+    const unsigned char* sb = smem + ST * kStage;
+    // ---- S^T = K Q^T for the four 32-key blocks of the tile
+    v16f s[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+      const uint4 k0 = *(const uint4*)(sb + kb * 2048 + koff0), k1 = *(const uint4*)(sb + kb * 2048 + koff1);
+      v8i kf;
+      kf[0] = (int)k0.x; kf[1] = (int)k0.y; kf[2] = (int)k0.z; kf[3] = (int)k0.w;
+      kf[4] = (int)k1.x; kf[5] = (int)k1.y; kf[6] = (int)k1.z; kf[7] = (int)k1.w;
+      v16f z;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) z[r] = 0.f;
+      s[kb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kf, qf, z, 0, 0, 0, UNIT, 0, UNIT);
+    }
+    // ---- tile maximum of this lane's query (64 of its 128 keys here, the rest in lane ^ 32)
+    float tm = s[0][0];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tm = __builtin_fmaxf(tm, s[kb][r]);
+    tm = xor32_max(tm);
+    const bool need = (t == 0) | (tm > THR);
+    if (__any(need)) {
+      float one;
+      asm volatile("v_mov_b32 %0, 1.0" : "=v"(one));
+      const float target = clamp448m(mrow + tm - PSHIFT);
+      const uint32_t b_hi = pack_fp8x4m(target, 0.f, 0.f, 0.f) & 0xffu;
+      const float m_hi = fp8_to_f32m(b_hi);
+      const uint32_t b_lo = pack_fp8x4m(target - m_hi, 0.f, 0.f, 0.f) & 0xffu;
+      const float mnew = need ? (m_hi + fp8_to_f32m(b_lo)) : mrow;
+      const float delta = (mnew - mrow) * one;
+      mrow += delta;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kb][r] -= delta;
+      if (t > 0) {
+        // O^T of query block a sits in lanes (q' = lane & 15, any g): the factor of query 16 a + q' comes from lane 16 a + q'
+        const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          const float al = __shfl(alpha, (lane & 15) + 16 * a, 64);
+#pragma unroll
+          for (int d = 0; d < 3; ++d) o[a][d] *= al;
+        }
+      }
+      if (hh == 1 && need) {       // bytes 8, 9 of this lane's operand half (columns 40, 41) <- e4m3(-m_hi), e4m3(-m_lo)
+        const unsigned neg = (b_hi ^ 0x80u) | ((b_lo ^ 0x80u) << 8);
+        qf[2] = (int)(((unsigned)qf[2] & 0xffff0000u) | neg);
+      }
+    }
+    // ---- p = 2^s as e4m3: the lane's 64 values in MFMA order = bytes 0..31 (blocks 0, 1: U) and 32..63 (blocks 2, 3: W)
+    v8i U, W;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const uint32_t pk = pack_fp8x4m(__builtin_amdgcn_exp2f(s[kb][4 * w]), __builtin_amdgcn_exp2f(s[kb][4 * w + 1]),
+                                        __builtin_amdgcn_exp2f(s[kb][4 * w + 2]), __builtin_amdgcn_exp2f(s[kb][4 * w + 3]));
+        if (kb < 2) U[(kb & 1) * 4 + w] = (int)pk;
+        else W[(kb & 1) * 4 + w] = (int)pk;
+      }
+    }
+    // lanes l and l ^ 16 exchange: U row 1 <-> W row 0, U row 3 <-> W row 2 (rows of 16 lanes).  Afterwards U is the P^T
+    // operand of query block 0 (k-group g = lane row: [U, W of lane q'; U, W of lane q' + 32]) and W that of block 1.
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const auto r = __builtin_amdgcn_permlane16_swap((unsigned)U[i], (unsigned)W[i], false, false);
+      U[i] = (int)r[0];
+      W[i] = (int)r[1];
+    }
+    // ---- O^T += V^T P^T over the 128 contraction slots
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const uint4 v0 = *(const uint4*)(sb + d * 2048 + voff0), v1 = *(const uint4*)(sb + d * 2048 + voff1);
+      v8i vf;
+      vf[0] = (int)v0.x; vf[1] = (int)v0.y; vf[2] = (int)v0.z; vf[3] = (int)v0.w;
+      vf[4] = (int)v1.x; vf[5] = (int)v1.y; vf[6] = (int)v1.z; vf[7] = (int)v1.w;
+      o[0][d] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(vf, U, o[0][d], 0, 0, 0, UNIT, 0, UNIT);
+      o[1][d] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(vf, W, o[1][d], 0, 0, 0, UNIT, 0, UNIT);
+    }
+    if (t + 1 < ntiles) wait_tiles_ahead((NST > 2 && t + 2 < ntiles) ? 1 : 0);
+    __syncthreads();
+  };
+  for (int t0 = 0; t0 < ntiles; t0 += NST) {
+    static_for_n<NST>([&](auto sc) __attribute__((always_inline)) {
+      const int t = t0 + decltype(sc)::value;
+      if (t < ntiles) tile(t, sc);
+    });
+  }
+
+  // ---- normalise and store: lane (q' = lane & 15, g) holds rows d = 16 db + 4 g + r of query 16 a + q'; the row sum is row 40
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const float l = __shfl(o[a][2][0], (lane & 15) + 32, 64);          // d = 40: block 2, g = 2, r = 0
+    const float inv = 1.0f / l;
+    const int q = qb * 128 + wave * 32 + 16 * a + (lane & 15);
+    bf16_t* op = out + ((size_t)b * N + q) * C + (size_t)h * kD;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const int dd = d * 16 + 4 * vg;
+      if (dd >= kD) continue;
+      const f32x4 v = o[a][d] * inv;
+      *(uint2*)(op + dd) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+    }
+  }
+}
+
+int g_mx_mode = 1;      // 1: head dim 40 with N % 128 == 0 runs on the scaled MFMAs; 0: attention_fp8.hip everywhere
+
+}  // namespace
+
+void attention_mx_set_mode(int m) { g_mx_mode = m ? 1 : 0; }
+int attention_mx_get_mode() { return g_mx_mode; }
+bool attention_mx_ok(int N, int C, int heads) { return g_mx_mode && heads > 0 && C / heads == kD && N % kTile == 0 && N >= kTile; }
+size_t attention_mx_scratch_bytes(int B, int N, int C, int heads) {
+  return attention_mx_ok(N, C, heads) ? (size_t)B * heads * (N / kTile) * (kKB + kVB) : 0;
+}
+
+int launch_attention_mx(const void* qkv, void* kv8, void* out, int B, int N, int C, int heads, hipStream_t s) {
+  if (!attention_mx_ok(N, C, heads)) return -2;
+  unsigned char* k8 = (unsigned char*)kv8;
+  unsigned char* v8 = k8 + (size_t)B * heads * (N / kTile) * kKB;
+  hipLaunchKernelGGL(kv_to_mx_kernel, dim3(N / kTile, heads, B), dim3(256), 0, s, (const bf16_t*)qkv, k8, v8, N, C, heads);
+  constexpr int NST = 3;
+  const size_t lds = (size_t)NST * kStage;
+  auto kern = attn_mx_kernel<NST>;
+  static bool attr_set[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!attr_set[dev]) {
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set[dev] = true;
+  }
+  const float scale_log2e = (1.0f / sqrtf((float)kD)) * 1.4426950408889634f;
+  hipLaunchKernelGGL(kern, dim3((N / 128) * heads * B), dim3(256), lds, s, (const bf16_t*)qkv, k8, v8, (bf16_t*)out, N, C, heads,
+                     scale_log2e);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+}  // namespace ldmseg

@@ -1721,7 +1721,8 @@ int ldmseg_debug_set(int key, int value) {
   if (key == 11) { gn_poll = value; groupnorm_set_coop(gn_mode, gn_poll); return 0; }
   if (key == 12) { mlp_fused_set_mode(value); ++g_plan_epoch; return 0; }
   if (key == 13) { mlp_fused_set_dbg(value); return 0; }
-  if (key == 14) { step_tail_set_mode(value); return 0; }   // bit 0: dedicated conv_out kernel (bf16); bit 1: scheduler step in its epilogue   // bit 8: no start-chunk rotation (bits 0-7: ablate builds)   // transformer feed-forward fusion: bit 0 MLP, bit 1 + proj_out
+  if (key == 14) { step_tail_set_mode(value); return 0; }
+  if (key == 15) { attention_mx_set_mode(value); ++g_plan_epoch; return 0; }   // fp8 attention: 1 = scaled MFMAs where the shape allows (default), 0 = unscaled   // bit 0: dedicated conv_out kernel (bf16); bit 1: scheduler step in its epilogue   // bit 8: no start-chunk rotation (bits 0-7: ablate builds)   // transformer feed-forward fusion: bit 0 MLP, bit 1 + proj_out
   if (key == 6 || key == 7) { ops_bench_knob(key, value); return 0; }   // ldmseg_bench_igemm: 6 = weight copies rotated, 7 = folded-LN launch   // bits 0-7 ablation flags (LDMSEG_IGEMM_ABLATE builds), bits 8-12 tile policy
   static unsigned long long ts_ptr = 0;                // keys 3/4: low/high half of a device stamp buffer (ablate builds)
   if (key == 3) { ts_ptr = (ts_ptr & 0xffffffff00000000ull) | (unsigned)value; igemm_set_tsbuf((void*)(uintptr_t)ts_ptr); return 0; }
@@ -1735,6 +1736,7 @@ int ldmseg_debug_get(int key) {
   if (key == 9) return igemm_get_cm_mode();
   if (key == 12) return mlp_fused_get_mode();
   if (key == 14) return step_tail_get_mode();
+  if (key == 15) return attention_mx_get_mode();
   if (key == 10) { const long long n = gn_coop_fallbacks(nullptr); return n > 0x7fffffffll ? 0x7fffffff : (int)n; }   // ring regions (ldmseg_op_* launches)
   return 0;
 }

@@ -183,6 +183,12 @@ int launch_rowsum(const void* W, const float* add, float* out, int N, int K, int
 // fp8 (e4m3) operand path of the bf16 attention for the long-context levels (attention_fp8.hip): head dims 40 / 80 only
 size_t attention_fp8_scratch_bytes(int B, int N, int C, int heads);
 int launch_attention_fp8(const void* qkv, void* kv8_scratch, void* out, int B, int N, int C, int heads, hipStream_t s);
+// the same on the 2x-rate block-scaled MFMAs (attention_mx.hip): head dim 40, N a multiple of 128; launch_attention_fp8 routes to it
+bool attention_mx_ok(int N, int C, int heads);
+size_t attention_mx_scratch_bytes(int B, int N, int C, int heads);
+int launch_attention_mx(const void* qkv, void* kv8_scratch, void* out, int B, int N, int C, int heads, hipStream_t s);
+void attention_mx_set_mode(int m);          // 0: keep attention_fp8.hip's unscaled MFMAs everywhere (A/B)
+int attention_mx_get_mode();
 
 // NCHW f32 [B,C,HW] -> NHWC compute dtype [B,HW,Cpad] (zero padded channels), optional affine a*x+b
 int launch_pack_nchw(const float* x, void* y, int B, int C, int HW, int Cpad, float mul, float add,
