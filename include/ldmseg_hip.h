@@ -279,7 +279,8 @@ int ldmseg_profile_dump(const char* path);
  * proj_out; default 3, 0 = the unfused launches); key 13 bit 8 = no start-chunk rotation in that kernel; key 14 = step tail
  * (bit 0: dedicated conv_out kernel in bf16, bit 1: the sampling loop's scheduler step / self-condition / next-input pack in
  * its epilogue; default 3); key 15 = fp8 attention on the block-scaled 2x-rate MFMAs where the shape allows (head dim 40,
- * tokens a multiple of 128; default 1, 0 = the unscaled fp8 MFMAs of attention_fp8.hip). */
+ * tokens a multiple of 128; default 1, 0 = the unscaled fp8 MFMAs of attention_fp8.hip; 0x111 = scaled MFMAs with exp +
+ * convert instead of the direct e4m3 byte - attention_mx.hip). */
 int ldmseg_debug_set(int key, int value);
 /* current value of a knob (key 1); key -1 = the shipped default of key 1.  Tests restore through this, never a literal.
  * key 10 = number of cooperative-GroupNorm workgroups that took the self-computing path in ldmseg_op_* launches so far. */

@@ -108,18 +108,27 @@ __global__ __launch_bounds__(256) void kv_to_mx_kernel(const bf16_t* __restrict_
   }
 }
 
-template <int NST>
-__global__ __launch_bounds__(256, 3) void attn_mx_kernel(const bf16_t* __restrict__ qkv, const unsigned char* __restrict__ k8,
+template <int NST, int NW, bool FEXP>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 3) void attn_mx_kernel(const bf16_t* __restrict__ qkv, const unsigned char* __restrict__ k8,
                                                          const unsigned char* __restrict__ v8, bf16_t* __restrict__ out, int N, int C,
-                                                         int heads, float scale_log2e) {
-  constexpr float PSHIFT = 7.0f, THR = PSHIFT + 1.25f;     // (see attention_fp8.hip: p uses the top of the e4m3 range)
+                                                         int heads, float scale_log2e, float pshift) {
+  // Exact form: p = 2^(s - m + 7) through v_exp_f32 + v_cvt_pk_fp8_f32 (p uses the top of the e4m3 range, see attention_fp8.hip).
+  // FEXP: the e4m3 BYTE of p is built directly.  An e4m3 number is 2^(e-7) (1 + f/8) with byte 8e + f, i.e. byte ~ 8 log2 p + 56
+  // with the mantissa interpolated linearly (2^x ~ 1 + x on [0, 1): within +6 % / centred by a constant: +-3 %, the size of the
+  // e4m3 rounding step itself).  The QK^T product leaves the MFMA times 8 for free (E8M0 scale 2^3 on the Q operand), the
+  // folded reference is m - pshift (pshift ~ 13.96: score = maximum <-> byte 112 - 0.3), and ONE v_cvt_pk_u8_f32 per score
+  // (saturating at 0) replaces v_exp_f32 + half a v_cvt_pk_fp8_f32: 64 instead of ~140 VALU slots per 128-key tile and wave.
+  // Row sums come out of the same bytes through the ones row of V^T, so numerator and denominator see the same weights.
+  const float PSHIFT = FEXP ? pshift : 7.0f, THR = PSHIFT + 1.25f;
+  constexpr float SMUL = FEXP ? 8.0f : 1.0f;                // scores are SMUL x (log2 units)
   constexpr int UNIT = 0x7f7f7f7f;                          // E8M0 scale 2^0 for every 32-element block
+  constexpr int QSCALE = FEXP ? (int)0x82828282 : UNIT;     // 2^3 on the Q operand's blocks
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ql = lane & 31, hh = lane >> 5;                 // QK^T result: query column, key half
   const int ntiles = N / kTile;
-  const int nqb = N / 128;                                  // 128 queries per workgroup (32 per wave)
+  const int nqb = N / (32 * NW);                            // 32 queries per wave
   int wg;
   {
     const int nwg = gridDim.x, bid = blockIdx.x;
@@ -133,15 +142,16 @@ __global__ __launch_bounds__(256, 3) void attn_mx_kernel(const bf16_t* __restric
   const unsigned char* vbase = v8 + (size_t)bh * ntiles * kVB;
   const unsigned lds0 = (unsigned)(uintptr_t)((__attribute__((address_space(3))) unsigned char*)smem);
 
-  // ---- DMA stream: a tile is 8 K pieces + 6 V^T pieces of 1 KiB; wave w issues pieces w, w+4, w+8 (, w+12)
-  const int my_cnt = wave < 2 ? 4 : 3;
+  // ---- DMA stream: a tile is 8 K pieces + 6 V^T pieces of 1 KiB; wave w issues pieces w, w + NW, ...
+  constexpr int PPW = (14 + NW - 1) / NW;
+  const int my_cnt = (14 - wave + NW - 1) / NW;             // pieces of this wave per tile
   auto issue_tile = [&](int t, int stage) __attribute__((always_inline)) {
     const unsigned char* kt = kbase + (size_t)t * kKB + lane * 16;
     const unsigned char* vt = vbase + (size_t)t * kVB + lane * 16;
     const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + stage * kStage);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int p = wave + 4 * j;
+    for (int j = 0; j < PPW; ++j) {
+      const int p = wave + NW * j;
       if (p < 8) glds16m(kt + p * 1024, dst + p * 1024);
       else if (p < 14) glds16m(vt + (p - 8) * 1024, dst + p * 1024);
     }
@@ -149,7 +159,9 @@ __global__ __launch_bounds__(256, 3) void attn_mx_kernel(const bf16_t* __restric
   auto wait_tiles_ahead = [&](int ahead) __attribute__((always_inline)) {
     if (ahead == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if (my_cnt == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if (my_cnt == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if (my_cnt == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
   };
 #pragma unroll
   for (int j = 0; j < NST - 1; ++j)
@@ -157,7 +169,7 @@ __global__ __launch_bounds__(256, 3) void attn_mx_kernel(const bf16_t* __restric
 
   // ---- Q operand (B of the 32x32x64 product): lane (q = ql, half hh) holds bytes 32 hh .. 32 hh + 31 of its row: d^-1/2 log2 e
   // scaled e4m3; columns 40, 41 (the folded maximum) start at zero and live in bytes 8, 9 of the hh = 1 lanes
-  const int q_row = qb * 128 + wave * 32 + ql;
+  const int q_row = qb * (32 * NW) + wave * 32 + ql;
   v8i qf;
   {
     const bf16_t* qp = qkv + ((size_t)b * N + q_row) * ld + (size_t)h * kD;
@@ -200,12 +212,8 @@ __global__ __launch_bounds__(256, 3) void attn_mx_kernel(const bf16_t* __restric
   wait_tiles_ahead((NST > 2 && ntiles > 1) ? 1 : 0);
   __syncthreads();
 
-  auto tile = [&](int t, auto stage_c) __attribute__((always_inline)) {
-    constexpr int ST = decltype(stage_c)::value;
-    if (t + NST - 1 < ntiles) issue_tile(t + NST - 1, (ST + NST - 1) % NST);
-    const unsigned char* sb = smem + ST * kStage;
-    // ---- S^T = K Q^T for the four 32-key blocks of the tile
-    v16f s[4];
+  // S^T = K Q^T for the four 32-key blocks of the tile in stage `sb`
+  auto qk = [&](const unsigned char* sb, v16f (&s)[4]) __attribute__((always_inline)) {
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
       const uint4 k0 = *(const uint4*)(sb + kb * 2048 + koff0), k1 = *(const uint4*)(sb + kb * 2048 + koff1);
@@ -215,66 +223,84 @@ __global__ __launch_bounds__(256, 3) void attn_mx_kernel(const bf16_t* __restric
       v16f z;
 #pragma unroll
       for (int r = 0; r < 16; ++r) z[r] = 0.f;
-      s[kb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kf, qf, z, 0, 0, 0, UNIT, 0, UNIT);
+      s[kb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kf, qf, z, 0, 0, 0, UNIT, 0, QSCALE);
     }
-    // ---- tile maximum of this lane's query (64 of its 128 keys here, the rest in lane ^ 32)
-    float tm = s[0][0];
+  };
+  auto tile_max = [&](const v16f (&s)[4]) __attribute__((always_inline)) -> float {
+    float m0 = s[0][0], m1 = s[1][0], m2 = s[2][0], m3 = s[3][0];
+#pragma unroll
+    for (int r = 1; r < 16; r += 2) {
+      m0 = __builtin_fmaxf(__builtin_fmaxf(m0, s[0][r]), s[0][r + 1 < 16 ? r + 1 : r]);
+      m1 = __builtin_fmaxf(__builtin_fmaxf(m1, s[1][r]), s[1][r + 1 < 16 ? r + 1 : r]);
+      m2 = __builtin_fmaxf(__builtin_fmaxf(m2, s[2][r]), s[2][r + 1 < 16 ? r + 1 : r]);
+      m3 = __builtin_fmaxf(__builtin_fmaxf(m3, s[3][r]), s[3][r + 1 < 16 ? r + 1 : r]);
+    }
+    return __builtin_fmaxf(__builtin_fmaxf(m0, m1), __builtin_fmaxf(m2, m3));
+  };
+  // the folded maximum follows a row that outgrew it (rare after the first tiles): the scores in `s` were computed against the
+  // old value and are corrected, the accumulated O^T is rescaled, columns 40 / 41 of Q take the new two-part value
+  auto move_max = [&](v16f (&s)[4], float tm, bool first) __attribute__((always_inline)) {
+    const bool need = first | (tm > THR * SMUL);
+    if (!__any(need)) return;
+    float one;
+    asm volatile("v_mov_b32 %0, 1.0" : "=v"(one));
+    const float target = clamp448m(mrow + tm * (1.0f / SMUL) - PSHIFT);
+    const uint32_t b_hi = pack_fp8x4m(target, 0.f, 0.f, 0.f) & 0xffu;
+    const float m_hi = fp8_to_f32m(b_hi);
+    const uint32_t b_lo = pack_fp8x4m(target - m_hi, 0.f, 0.f, 0.f) & 0xffu;
+    const float mnew = need ? (m_hi + fp8_to_f32m(b_lo)) : mrow;
+    const float delta = (mnew - mrow) * one;
+    mrow += delta;
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) tm = __builtin_fmaxf(tm, s[kb][r]);
-    tm = xor32_max(tm);
-    const bool need = (t == 0) | (tm > THR);
-    if (__any(need)) {
-      float one;
-      asm volatile("v_mov_b32 %0, 1.0" : "=v"(one));
-      const float target = clamp448m(mrow + tm - PSHIFT);
-      const uint32_t b_hi = pack_fp8x4m(target, 0.f, 0.f, 0.f) & 0xffu;
-      const float m_hi = fp8_to_f32m(b_hi);
-      const uint32_t b_lo = pack_fp8x4m(target - m_hi, 0.f, 0.f, 0.f) & 0xffu;
-      const float mnew = need ? (m_hi + fp8_to_f32m(b_lo)) : mrow;
-      const float delta = (mnew - mrow) * one;
-      mrow += delta;
+      for (int r = 0; r < 16; ++r) s[kb][r] -= delta * SMUL;
+    if (!first) {
+      // O^T of query block a sits in lanes (q' = lane & 15, any g): the factor of query 16 a + q' comes from lane 16 a + q'
+      const float alpha = __builtin_amdgcn_exp2f(-delta);
 #pragma unroll
-      for (int kb = 0; kb < 4; ++kb)
+      for (int a = 0; a < 2; ++a) {
+        const float al = __shfl(alpha, (lane & 15) + 16 * a, 64);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[kb][r] -= delta;
-      if (t > 0) {
-        // O^T of query block a sits in lanes (q' = lane & 15, any g): the factor of query 16 a + q' comes from lane 16 a + q'
-        const float alpha = __builtin_amdgcn_exp2f(-delta);
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-          const float al = __shfl(alpha, (lane & 15) + 16 * a, 64);
-#pragma unroll
-          for (int d = 0; d < 3; ++d) o[a][d] *= al;
-        }
-      }
-      if (hh == 1 && need) {       // bytes 8, 9 of this lane's operand half (columns 40, 41) <- e4m3(-m_hi), e4m3(-m_lo)
-        const unsigned neg = (b_hi ^ 0x80u) | ((b_lo ^ 0x80u) << 8);
-        qf[2] = (int)(((unsigned)qf[2] & 0xffff0000u) | neg);
+        for (int d = 0; d < 3; ++d) o[a][d] *= al;
       }
     }
-    // ---- p = 2^s as e4m3: the lane's 64 values in MFMA order = bytes 0..31 (blocks 0, 1: U) and 32..63 (blocks 2, 3: W)
-    v8i U, W;
+    if (hh == 1 && need) {       // bytes 8, 9 of this lane's operand half (columns 40, 41) <- e4m3(-m_hi), e4m3(-m_lo)
+      const unsigned neg = (b_hi ^ 0x80u) | ((b_lo ^ 0x80u) << 8);
+      qf[2] = (int)(((unsigned)qf[2] & 0xffff0000u) | neg);
+    }
+  };
+  // p = 2^s as e4m3: the lane's 64 values in MFMA order = bytes 0..31 (blocks 0, 1: U) and 32..63 (blocks 2, 3: W); then lanes
+  // l and l ^ 16 exchange U row 1 <-> W row 0, U row 3 <-> W row 2 (rows of 16 lanes): afterwards U is the P^T operand of
+  // query block 0 (k-group g = lane row: [U, W of lane q'; U, W of lane q' + 32]) and W that of block 1
+  auto softmax = [&](v16f (&s)[4], v8i& U, v8i& W) __attribute__((always_inline)) {
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
-        const uint32_t pk = pack_fp8x4m(__builtin_amdgcn_exp2f(s[kb][4 * w]), __builtin_amdgcn_exp2f(s[kb][4 * w + 1]),
-                                        __builtin_amdgcn_exp2f(s[kb][4 * w + 2]), __builtin_amdgcn_exp2f(s[kb][4 * w + 3]));
+        uint32_t pk;
+        if constexpr (FEXP) {
+          pk = __builtin_amdgcn_cvt_pk_u8_f32(s[kb][4 * w], 0, 0u);
+          pk = __builtin_amdgcn_cvt_pk_u8_f32(s[kb][4 * w + 1], 1, pk);
+          pk = __builtin_amdgcn_cvt_pk_u8_f32(s[kb][4 * w + 2], 2, pk);
+          pk = __builtin_amdgcn_cvt_pk_u8_f32(s[kb][4 * w + 3], 3, pk);
+        } else {
+          pk = pack_fp8x4m(__builtin_amdgcn_exp2f(s[kb][4 * w]), __builtin_amdgcn_exp2f(s[kb][4 * w + 1]),
+                           __builtin_amdgcn_exp2f(s[kb][4 * w + 2]), __builtin_amdgcn_exp2f(s[kb][4 * w + 3]));
+        }
         if (kb < 2) U[(kb & 1) * 4 + w] = (int)pk;
         else W[(kb & 1) * 4 + w] = (int)pk;
       }
     }
-    // lanes l and l ^ 16 exchange: U row 1 <-> W row 0, U row 3 <-> W row 2 (rows of 16 lanes).  Afterwards U is the P^T
-    // operand of query block 0 (k-group g = lane row: [U, W of lane q'; U, W of lane q' + 32]) and W that of block 1.
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const auto r = __builtin_amdgcn_permlane16_swap((unsigned)U[i], (unsigned)W[i], false, false);
       U[i] = (int)r[0];
       W[i] = (int)r[1];
     }
-    // ---- O^T += V^T P^T over the 128 contraction slots
+  };
+  // O^T += V^T P^T over the 128 contraction slots of the tile in stage `sb`
+  auto pv = [&](const unsigned char* sb, const v8i& U, const v8i& W) __attribute__((always_inline)) {
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
       const uint4 v0 = *(const uint4*)(sb + d * 2048 + voff0), v1 = *(const uint4*)(sb + d * 2048 + voff1);
@@ -284,14 +310,31 @@ __global__ __launch_bounds__(256, 3) void attn_mx_kernel(const bf16_t* __restric
       o[0][d] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(vf, U, o[0][d], 0, 0, 0, UNIT, 0, UNIT);
       o[1][d] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(vf, W, o[1][d], 0, 0, 0, UNIT, 0, UNIT);
     }
-    if (t + 1 < ntiles) wait_tiles_ahead((NST > 2 && t + 2 < ntiles) ? 1 : 0);
-    __syncthreads();
   };
-  for (int t0 = 0; t0 < ntiles; t0 += NST) {
-    static_for_n<NST>([&](auto sc) __attribute__((always_inline)) {
-      const int t = t0 + decltype(sc)::value;
-      if (t < ntiles) tile(t, sc);
-    });
+  {
+    // QK^T, maximum, softmax, PV one after the other; several waves per SIMD overlap each other's phases.  (Two more forms were
+    // built and measured at N = 16384, B = 4: a software-pipelined loop that issues tile t+1's QK^T between tile t's exp / convert
+    // instructions - 206 registers, 2 waves per SIMD, 1.69 ms against 1.36 - and a ping-pong form whose two workgroup halves run
+    // MFMA and VALU phases one barrier apart - 1.40 ms: the matrix pipe and the VALU of a SIMD do not overlap to any useful
+    // degree on this part, whatever the arrangement; the time is the SUM of the two streams.)
+    for (int t0 = 0; t0 < ntiles; t0 += NST) {
+      static_for_n<NST>([&](auto sc) __attribute__((always_inline)) {
+        constexpr int ST = decltype(sc)::value;
+        const int t = t0 + ST;
+        if (t < ntiles) {
+          if (t + NST - 1 < ntiles) issue_tile(t + NST - 1, (ST + NST - 1) % NST);
+          const unsigned char* sb = smem + ST * kStage;
+          v16f s[4];
+          qk(sb, s);
+          move_max(s, xor32_max(tile_max(s)), t == 0);
+          v8i U, W;
+          softmax(s, U, W);
+          pv(sb, U, W);
+          if (t + 1 < ntiles) wait_tiles_ahead((NST > 2 && t + 2 < ntiles) ? 1 : 0);
+          __syncthreads();
+        }
+      });
+    }
   }
 
   // ---- normalise and store: lane (q' = lane & 15, g) holds rows d = 16 db + 4 g + r of query 16 a + q'; the row sum is row 40
@@ -299,7 +342,7 @@ __global__ __launch_bounds__(256, 3) void attn_mx_kernel(const bf16_t* __restric
   for (int a = 0; a < 2; ++a) {
     const float l = __shfl(o[a][2][0], (lane & 15) + 32, 64);          // d = 40: block 2, g = 2, r = 0
     const float inv = 1.0f / l;
-    const int q = qb * 128 + wave * 32 + 16 * a + (lane & 15);
+    const int q = qb * (32 * NW) + wave * 32 + 16 * a + (lane & 15);
     bf16_t* op = out + ((size_t)b * N + q) * C + (size_t)h * kD;
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
@@ -312,10 +355,17 @@ __global__ __launch_bounds__(256, 3) void attn_mx_kernel(const bf16_t* __restric
 }
 
 int g_mx_mode = 1;      // 1: head dim 40 with N % 128 == 0 runs on the scaled MFMAs; 0: attention_fp8.hip everywhere
+int g_mx_variant = 3;   // bit 0: 8-wave workgroups (256 queries share a K/V tile); bit 1: direct e4m3 byte instead of exp + convert
+float g_mx_pshift = 13.95f;     // FEXP: folded reference = maximum - pshift (byte of the maximum = 8 pshift = 111.6: the -0.4 centres the
+                                // interpolation error; measured optimum of tools/attn8_acc.py, rel-L2 1.2 x the exact-exp form's)
 
 }  // namespace
 
-void attention_mx_set_mode(int m) { g_mx_mode = m ? 1 : 0; }
+void attention_mx_set_mode(int m) {    // bit 0: on / off; bit 8: variant from bits 4-5, bit 9: pshift = 13 + bits 16.. / 1000 (else the defaults)
+  g_mx_mode = (m & 1) ? 1 : 0;
+  g_mx_variant = (m & 0x100) ? ((m >> 4) & 3) : 3;
+  g_mx_pshift = (m & 0x200) ? 13.0f + (float)((m >> 16) & 0xfff) * 1e-3f : 13.95f;
+}
 int attention_mx_get_mode() { return g_mx_mode; }
 bool attention_mx_ok(int N, int C, int heads) { return g_mx_mode && heads > 0 && C / heads == kD && N % kTile == 0 && N >= kTile; }
 size_t attention_mx_scratch_bytes(int B, int N, int C, int heads) {
@@ -327,19 +377,26 @@ int launch_attention_mx(const void* qkv, void* kv8, void* out, int B, int N, int
   unsigned char* k8 = (unsigned char*)kv8;
   unsigned char* v8 = k8 + (size_t)B * heads * (N / kTile) * kKB;
   hipLaunchKernelGGL(kv_to_mx_kernel, dim3(N / kTile, heads, B), dim3(256), 0, s, (const bf16_t*)qkv, k8, v8, N, C, heads);
-  constexpr int NST = 3;
-  const size_t lds = (size_t)NST * kStage;
-  auto kern = attn_mx_kernel<NST>;
-  static bool attr_set[64] = {};
+  const float scale_log2e = (1.0f / sqrtf((float)kD)) * 1.4426950408889634f;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-  if (!attr_set[dev]) {
-    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set[dev] = true;
+  auto go = [&](auto kern, int nst, int nw, bool* attr) {
+    const size_t lds = (size_t)nst * kStage;
+    if (!attr[dev]) {
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr[dev] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((N / (32 * nw)) * heads * B), dim3(64 * nw), lds, s, (const bf16_t*)qkv, k8, v8, (bf16_t*)out, N, C,
+                       heads, scale_log2e, g_mx_pshift);
+  };
+  static bool a0[64] = {}, a1[64] = {}, a2[64] = {}, a3[64] = {};
+  const int variant = (N % 256 == 0) ? g_mx_variant : (g_mx_variant & 2);      // 8-wave workgroups own 256 queries
+  switch (variant) {
+    case 0: go(attn_mx_kernel<3, 4, false>, 3, 4, a0); break;
+    case 1: go(attn_mx_kernel<3, 8, false>, 3, 8, a1); break;
+    case 2: go(attn_mx_kernel<3, 4, true>, 3, 4, a2); break;
+    default: go(attn_mx_kernel<3, 8, true>, 3, 8, a3); break;
   }
-  const float scale_log2e = (1.0f / sqrtf((float)kD)) * 1.4426950408889634f;
-  hipLaunchKernelGGL(kern, dim3((N / 128) * heads * B), dim3(256), lds, s, (const bf16_t*)qkv, k8, v8, (bf16_t*)out, N, C, heads,
-                     scale_log2e);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

@@ -544,7 +544,9 @@ def fp8_e4m3_round(t):
     return t.clamp(-448, 448).to(torch.float8_e4m3fn).to(torch.float32)
 
 
-@pytest.mark.parametrize("mx", [1, 0])     # 1: block-scaled 2x-rate MFMAs where the shape allows (attention_mx.hip), 0: unscaled fp8 MFMAs
+# 1: block-scaled 2x-rate MFMAs where the shape allows (attention_mx.hip), probabilities as direct e4m3 bytes (the shipped form);
+# 0x111: the same with exp + convert; 0: unscaled fp8 MFMAs (attention_fp8.hip)
+@pytest.mark.parametrize("mx", [1, 0x111, 0])
 @pytest.mark.parametrize("B,N,Cc", [(1, 256, 320), (2, 1024, 320), (1, 200, 640), (1, 4096, 640), (1, 4096, 320), (1, 100, 320),
                                     (2, 128, 320), (1, 384, 320)])
 def test_attention_fp8_path(L, B, N, Cc, mx):
@@ -577,8 +579,9 @@ def test_attention_fp8_path(L, B, N, Cc, mx):
     print(f"fp8 attention B={B} N={N} C={Cc}: vs fp64-on-quantised-operands {e_same:.3e}, vs unquantised {e_total:.3e} (rel-L2 {l2:.3e})")
     # measured on MI355X: 0.7-2.0e-2 against the same operands (P's e4m3 rounding; independent of N since the probabilities
     # are shifted to the top of the e4m3 range), 4-12e-2 max-norm / 3-5e-2 rel-L2 against the unquantised tensors (e4m3 Q, K, V
-    # on unit-variance random data, where the outputs are averages of noise)
-    assert e_same < 3e-2 and e_total < 0.2 and l2 < 0.1
+    # on unit-variance random data, where the outputs are averages of noise).  The direct-byte form interpolates the e4m3
+    # mantissa linearly: 1.8-2.5e-2 against the same operands (1.2 x the exact form in rel-L2), +2 % against the unquantised ones.
+    assert e_same < (4e-2 if mx == 1 else 3e-2) and e_total < 0.2 and l2 < 0.1
 
 
 def test_attention_fp8_long_context_vs_bf16_kernel(L):
