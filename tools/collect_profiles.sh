@@ -2,7 +2,7 @@
 # Run on the GPU box from the repo root (gpurun): every measurement profiles/ holds for one round, from ONE box.
 #   bash tools/collect_profiles.sh r02     -> gpurun_out/prof_r02/...;  then locally: python tools/import_profiles.py r02
 set -x
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_$TAG; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 BENCH="python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-images --no-extras --profile-steps 0"
@@ -13,7 +13,7 @@ rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -- $BENCH3 > $O/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE -d $O/pmc_mfma -- $BENCH3 > $O/pmc_mfma.log 2>&1
 for d in pmc_fetch pmc_write pmc_mfma; do
   python $R/tools/pmc_query.py $O/$d igemm_kernel > $O/$d.txt 2>&1
-  python $R/tools/pmc_query.py $O/$d attn3_kernel >> $O/$d.txt 2>&1
+  for k in mlp_fused_kernel conv_out_tail_kernel attn3_kernel; do python $R/tools/pmc_query.py $O/$d $k >> $O/$d.txt 2>&1; done
 done
 cd $R
 bash tools/trace_layers.sh bf16 8; cp gpurun_out/trace_layers.txt $O/trace_layers_b8_l64_bf16.txt; cp gpurun_out/layers.csv $O/per_launch_events.csv
@@ -21,9 +21,16 @@ python bench.py > $O/bench_default.json 2> $O/bench_default.err
 # BASELINE configs[4] as lines of their own (20 steps): bf16 attention and the fp8 attention path on the 16384-token level
 python bench.py --batch 4 --latent 128 --steps 20 --warmup 2 --no-cpu-baseline --no-extras --no-images > $O/bench_config4_b4_l128_bf16.json 2>/dev/null
 python bench.py --batch 4 --latent 128 --steps 20 --warmup 2 --attention-fp8 16384 --no-cpu-baseline --no-extras --no-images > $O/bench_config4_b4_l128_fp8attn.json 2>/dev/null
+# round 4: same-box comparisons
+python tools/yardstick.py --out $O/yardstick.txt > $O/yardstick.log 2>&1
+python tools/ff_bench.py 32768 65536 > $O/ff_bench.txt 2>&1
+python tools/attn8_bench.py > $O/attn8_bench.txt 2>&1; python tools/attn8_bench.py 4 4096 320 >> $O/attn8_bench.txt 2>&1
+python tools/attn8_acc.py 2>&1 | grep "N=" > $O/attn8_acc.txt
+python tools/ab_forward.py "12=0,14=0" "12=3,14=0" "12=3,14=1" --rounds 3 > $O/ab_knobs.txt 2>&1
+[ -f scratch/lib_r03.so ] && { LDMSEG_HIP_LIB=scratch/lib_r03.so python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras --no-images --no-torch-reference --profile-steps 0 > $O/bench_r03_lib_same_box.json 2>/dev/null; }
 python tools/kbench.py gn > $O/kbench_groupnorm.txt 2>&1
 python tools/kbench.py attn > $O/kbench_attention.txt 2>&1
-for u in mfma_lds mfma_lds2 buf_lds valu_trans copy_floor launch_floor; do [ -x tools/ubench/bin/$u ] && timeout 300 tools/ubench/bin/$u > $O/ubench_$u.txt 2>&1; done
+for u in mfma_lds mfma_lds2 buf_lds valu_trans copy_floor launch_floor barrier_cost mx_probe; do [ -x tools/ubench/bin/$u ] && timeout 300 tools/ubench/bin/$u > $O/ubench_$u.txt 2>&1; done
 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; tail -2 $O/pytest_gpu.log
 find $O -name "*.db" -delete; find $O -name "*kernel_trace.csv" -size +8M -delete
 du -sh $O

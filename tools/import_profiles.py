@@ -4,7 +4,7 @@
 import glob, json, os, re, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src, dst = os.path.join(ROOT, "gpurun_out", f"prof_{tag}"), os.path.join(ROOT, "profiles")
 
 
@@ -25,13 +25,15 @@ cp("per_launch_events.csv", "per_launch_events_unet_forward_b8_l64_bf16.csv")
 cp("trace_layers_b8_l64_bf16.txt", "kernel_trace_per_layer_b8_l64_bf16.txt")
 for n in ("pmc_fetch", "pmc_write", "pmc_mfma"):
     cp(n + ".txt", n + ".txt")
-for u in ("mfma_lds", "mfma_lds2", "buf_lds", "valu_trans", "copy_floor"):
+for u in ("mfma_lds", "mfma_lds2", "buf_lds", "valu_trans", "copy_floor", "launch_floor", "barrier_cost", "mx_probe"):
     cp(f"ubench_{u}.txt", f"ubench_{u}.txt")
 cp("pytest_gpu.log", "pytest_gpu.log")
 cp("bench_config4_b4_l128_bf16.json", "bench_config4_b4_l128_bf16.json")
 cp("bench_config4_b4_l128_fp8attn.json", "bench_config4_b4_l128_fp8attn.json")
 cp("kbench_groupnorm.txt", "kbench_groupnorm.txt")
 cp("kbench_attention.txt", "kbench_attention.txt")
+for n in ("yardstick.txt", "ff_bench.txt", "attn8_bench.txt", "attn8_acc.txt", "ab_forward_vs_r03.txt", "bench_r03_lib_same_box.json", "ab_knobs.txt"):
+    cp(n, n)
 
 
 def per_dispatch(path, counter, kernel):
@@ -44,7 +46,7 @@ def per_dispatch(path, counter, kernel):
         m = re.match(rf"{counter}\s+per-dispatch total\s+([\d.]+)", ln)
         if m:
             vals.append(float(m.group(1)))
-    ig = [(n, c) for n, c in names if kernel in n]
+    ig = [(n, c) for n, c in names if any(k in n for k in kernel.split("|"))]
     for (n, c), v in zip(ig, vals[:len(ig)]):
         tot_n += c
         tot_v += c * v
@@ -52,10 +54,10 @@ def per_dispatch(path, counter, kernel):
 
 
 try:
-    n_f, kib_f = per_dispatch(os.path.join(dst, f"{tag}_pmc_fetch.txt"), "FETCH_SIZE", "igemm_kernel")
-    n_w, kib_w = per_dispatch(os.path.join(dst, f"{tag}_pmc_write.txt"), "WRITE_SIZE", "igemm_kernel")
+    n_f, kib_f = per_dispatch(os.path.join(dst, f"{tag}_pmc_fetch.txt"), "FETCH_SIZE", "igemm_kernel|mlp_fused_kernel|conv_out_tail_kernel")
+    n_w, kib_w = per_dispatch(os.path.join(dst, f"{tag}_pmc_write.txt"), "WRITE_SIZE", "igemm_kernel|mlp_fused_kernel|conv_out_tail_kernel")
     import bench
-    out = {"kernel": "igemm_kernel (all instantiations)", "launches": n_f, "forwards": n_f // 162,
+    out = {"kernel": "igemm_kernel (all instantiations) + mlp_fused_kernel + conv_out_tail_kernel", "launches": n_f,
            "fetch_bytes_per_launch": 2 * 1024 * kib_f / n_f, "write_bytes_per_launch": 1024 * kib_w / n_w,
            "hbm_bytes_per_launch": 2 * 1024 * kib_f / n_f + 1024 * kib_w / n_w, "csrc_sha": bench.csrc_hash(),
            "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 3 --warmup 1 "

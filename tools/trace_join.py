@@ -6,7 +6,8 @@ trace, layers = sys.argv[1], sys.argv[2]
 NF = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 rows = list(csv.DictReader(open(trace)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-ig = [r for r in rows if "igemm_kernel" in r["Kernel_Name"]]
+FAM0 = ("igemm_kernel", "mlp_fused_kernel", "conv_out_tail_kernel")      # the launches ldmseg_profile_dump labels as family 0, in order
+ig = [r for r in rows if any(k in r["Kernel_Name"] for k in FAM0)]
 lab = [ln.split(",") for ln in open(layers).read().splitlines()[1:]]
 lab0 = [l for l in lab if l[0] == "0"]
 per_fwd = len(ig) // NF
@@ -17,16 +18,17 @@ agg = collections.OrderedDict()
 for f in range(2, NF):                              # skip the first two forwards (warm-up)
     for i in range(per_fwd):
         r = ig[f * per_fwd + i]; l = lab0[i]
-        name = r["Kernel_Name"]; name = name[name.find("<"):name.find(">") + 1].replace("__hip_bfloat16", "bf16")
+        name = r["Kernel_Name"]
+        name = (name[name.find("<"):name.find(">") + 1] if "igemm_kernel" in name else next(k for k in FAM0 if k in name)).replace("__hip_bfloat16", "bf16")
         a = agg.setdefault((l[1], name), [0, 0.0, 0.0]); a[0] += 1
         a[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3; a[2] += float(l[3])
 n = NF - 2
 tot = sum(a[1] for a in agg.values()) / n; fl = sum(a[2] for a in agg.values()) / n
-print(f"igemm kernels: {per_fwd} launches/forward, {tot:.1f} us/forward, {fl/tot/1e6:.1f} TFLOP/s")
+print(f"GEMM-family kernels (igemm + fused feed-forward + conv_out tail): {per_fwd} launches/forward, {tot:.1f} us/forward, {fl/tot/1e6:.1f} TFLOP/s")
 oth = collections.Counter(); 
 t0 = int(ig[2 * per_fwd]["Start_Timestamp"])
 for r in rows:
-    if int(r["Start_Timestamp"]) >= t0 and "igemm_kernel" not in r["Kernel_Name"]:
+    if int(r["Start_Timestamp"]) >= t0 and not any(k in r["Kernel_Name"] for k in FAM0):
         oth[r["Kernel_Name"][:60]] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3 / n
 for k, v in oth.most_common(14): print(f"   other {k:60s} {v:8.1f} us/forward")
 last = [r for r in rows if int(r["Start_Timestamp"]) >= t0]
