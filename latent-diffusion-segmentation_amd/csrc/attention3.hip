@@ -391,6 +391,8 @@ int run3(const void* qkv, void* out, int B, int N, int C, int heads, hipStream_t
 }  // namespace
 
 // bf16, head dim 40 or 80; returns -100 when the shape is not handled here (caller falls through to attention.hip)
+int launch_attention4(const void* qkv, void* out, int B, int N, int C, int heads, int variant, hipStream_t s);   // attention4.hip
+
 int launch_attention3(const void* qkv, void* out, int B, int N, int C, int heads, int variant, hipStream_t s) {
   const int d = C / heads;
   // variant: 0 = shipped choice; the others are alternatives kept for A/B measurements and the parity tests
@@ -403,9 +405,14 @@ int launch_attention3(const void* qkv, void* out, int B, int N, int C, int heads
     if (variant == 8) return run3<40, 2, 4, 3, false, 1, 8>(qkv, out, B, N, C, heads, s);     // 8 waves, maxima on every tile
     if (variant == 9) return run3<40, 2, 4, 3, false, 4, 8>(qkv, out, B, N, C, heads, s);
     if (variant == 10) return run3<40, 2, 3, 3, false, 16, 4>(qkv, out, B, N, C, heads, s);
+    if (variant >= 11 && variant <= 14) return launch_attention4(qkv, out, B, N, C, heads, variant - 11, s);   // attention4.hip, forced form
     // 8-wave workgroups: 256 query rows share every K / V tile (half the LDS-DMA instructions per score: issuing one parks
     // the wave for 60-185 cycles); short sequences keep the 4-wave form (too few workgroups otherwise)
-    if (variant == 0 && (long)B * heads * ((N + 255) / 256) >= 256) return run3<40, 2, 4, 3, false, 16, 8>(qkv, out, B, N, C, heads, s);
+    const bool big = (long)B * heads * ((N + 255) / 256) >= 256;
+    // shipped (0): the 32x32x16 score-block kernel of attention4.hip (round 4: N = 4096 at B = 8 224 -> 196 us, N = 16384 at B = 4
+    // 1.67 -> 1.49 ms, N = 1000 15.8 -> 14.1 us); 7: this file's kernel under the same rule (the round-3 choice), for A/B
+    if (variant == 0) return launch_attention4(qkv, out, B, N, C, heads, big ? 0 : 2, s);
+    if (big) return run3<40, 2, 4, 3, false, 16, 8>(qkv, out, B, N, C, heads, s);
     return run3<40, 2, 3, 3, false, 16, 4>(qkv, out, B, N, C, heads, s);
   }
   if (d == 80) {

@@ -451,12 +451,15 @@ def attn_variant(L):
     lib.ldmseg_debug_set(2, 0)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 8, 9, 10])
-@pytest.mark.parametrize("B,N,Cc", [(2, 1024, 320), (1, 200, 640), (1, 4096, 320), (8, 1024, 640), (8, 1024, 320)])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14])
+@pytest.mark.parametrize("B,N,Cc", [(2, 1024, 320), (1, 200, 640), (1, 4096, 320), (8, 1024, 640), (8, 1024, 320), (1, 200, 320), (3, 1000, 320),
+                                    (1, 33, 320)])
 def test_attention_variants(L, attn_variant, variant, B, N, Cc):
-    """Every selectable bf16 attention kernel (attention3.hip variants 0/1/4/5/6/8/9/10 - 4- and 8-wave workgroups, row
-    maxima looked at on every tile or every 4th / 16th -, attention.hip 2/3) vs the fp64 reference.  The batch-8 shapes have
-    enough workgroups for the shipped choice (0) to take its 8-wave form."""
+    """Every selectable bf16 attention kernel (attention3.hip variants 1/4/5/6/7/8/9/10 - 4- and 8-wave workgroups, row
+    maxima looked at on every tile or every 4th / 16th -, attention4.hip 11..14 - head dim 40 on 32x32x16 score blocks, 8 / 4
+    waves, lazy / every tile -, attention.hip 2/3, and the shipped rule 0) vs the fp64 reference.  The batch-8 shapes have
+    enough workgroups for the shipped choice to take its 8-wave form; 200 / 1000 / 33 tokens end in ragged key tiles and
+    partly empty query blocks."""
     g = torch.Generator().manual_seed(N + Cc + variant)
     qkv = torch.randn(B, N, 3 * Cc, generator=g)
     qkv[:, :, :Cc] *= 2.0
@@ -503,11 +506,12 @@ def test_attention_running_max_paths(L, case, Cc):
     assert rel_err(out, ref) < 1.5e-2, case
 
 
-@pytest.mark.parametrize("variant", [0, 9, 10])
+@pytest.mark.parametrize("variant", [0, 7, 9, 10, 13])
 @pytest.mark.parametrize("case", ["overflow_between_looks", "growth_between_looks"])
 @pytest.mark.parametrize("Cc", [320, 640])
 def test_attention_lazy_maxima(L, attn_variant, variant, case, Cc):
-    """The shipped kernels look at the row maxima only on tile 0 and every 16th (variant 9: 4th) key tile.  A key in a tile
+    """The shipped kernels (0: attention4.hip at head dim 40, attention3.hip at 80; 7 / 10 / 13: the round-3 rule and the 4-wave
+    forms) look at the row maxima only on tile 0 and every 16th (variant 9: 4th) key tile.  A key in a tile
     that is NOT looked at (tile 5) whose score exceeds everything seen before by (a) far more than fp32 can hold as
     exp2 - the row sum turns inf, the workgroup must notice and redo its rows with the maxima tracked on every tile -
     and (b) by 2^60 - no overflow, no redo: exp2 against the stale maximum must still give the right softmax."""

@@ -5,15 +5,15 @@ set -x
 TAG=${1:-r04}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_$TAG; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
-BENCH="python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-images --no-extras --profile-steps 0"
+BENCH="python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-images --no-extras --no-torch-reference --profile-steps 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o s -- $BENCH > $O/bench_under_rocprof.json 2> $O/stats.err
-BENCH3="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-images --no-extras --profile-steps 0"
+BENCH3="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-images --no-extras --no-torch-reference --profile-steps 0"
 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -- $BENCH3 > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -- $BENCH3 > $O/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE -d $O/pmc_mfma -- $BENCH3 > $O/pmc_mfma.log 2>&1
 for d in pmc_fetch pmc_write pmc_mfma; do
   python $R/tools/pmc_query.py $O/$d igemm_kernel > $O/$d.txt 2>&1
-  for k in mlp_fused_kernel conv_out_tail_kernel attn3_kernel; do python $R/tools/pmc_query.py $O/$d $k >> $O/$d.txt 2>&1; done
+  for k in mlp_fused_kernel conv_out_tail_kernel attn3_kernel attn4_kernel; do python $R/tools/pmc_query.py $O/$d $k >> $O/$d.txt 2>&1; done
 done
 cd $R
 bash tools/trace_layers.sh bf16 8; cp gpurun_out/trace_layers.txt $O/trace_layers_b8_l64_bf16.txt; cp gpurun_out/layers.csv $O/per_launch_events.csv
