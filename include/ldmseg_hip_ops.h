@@ -49,6 +49,13 @@ int ldmseg_op_panoptic_from_decoder(const float* x4, int B, int C, int H4, int W
                                     int64_t ignore_label, int32_t* labels, int32_t* panoptic, uint8_t* keep, int32_t* counts,
                                     int32_t* mask_counts, float* volume, void* stream);
 
+/* Entry of a transformer on caller-supplied weights: h = x Wp^T + bp (proj_in, /root/reference/ldmseg/models/unet.py:361-373 via
+ * diffusers Transformer2DModel), q|k|v = [Wq | Wk | Wv] LayerNorm(h; gamma, beta).  mode 0: unfused launches; 1: the row-local fused
+ * kernel (bf16, C = 320, M % 128 == 0).  h_out [M][C], qkv_out [M][3C] fp32.  time_iters > 0 also times the chosen path. */
+int ldmseg_op_transformer_in(const float* x, const float* wp, const float* bp, const float* gamma, const float* beta, const float* wq,
+                             const float* wk, const float* wv, int M, int C, float eps, int dtype, int mode, float* h_out, float* qkv_out,
+                             int time_iters, float* us_per_call, void* stream);
+
 /* One conv / GEMM layer launched exactly as the engine launches it inside a forward (NHWC operands, the engine's
  * split-K plan when splits == 0, row-major store epilogue with bias / per-image bias row / residual / SiLU, or GEGLU):
  * F.conv2d(cat([x,x2],1) [nearest x2 if up], w, bias, stride, k/2) + rowbias[b,:,None,None] + resid, then SiLU;

@@ -431,6 +431,8 @@ struct TransformerW {
   NormW norm, ln1, ln3;
   ConvW proj_in, qkv, attn_out, ff1, ff2, proj_out;
   void* mlp_stream = nullptr;   // 320-channel level, bf16: the feed-forward's weights as one consumption-ordered stream (tfuse.hip)
+  void* in_stream = nullptr;    // the same for proj_in | to_q | to_k | to_v (tproj.hip)
+  float* in_bias = nullptr;     // [4][C]: proj_in bias | W_q beta | W_k beta | W_v beta
 };
 
 }  // namespace
@@ -572,6 +574,15 @@ int build_transformer(Builder& b, const std::string& p, int C, TransformerW* t) 
     TRY(b.arena->alloc(&t->mlp_stream, sb));
     TRY(launch_pack_mlp_stream(t->ff1.w, t->ff2.w, t->proj_out.w, t->mlp_stream, C, b.s));
   }
+  if (const size_t sb = (dt == DT_BF16 && t->proj_in.N == C && t->proj_in.cin_pad == C && t->qkv.N == 3 * C) ? proj_qkv_stream_bytes(C) : 0) {
+    TRY(b.arena->alloc(&t->in_stream, sb));
+    TRY(launch_pack_proj_qkv_stream(t->proj_in.w, t->qkv.w, t->in_stream, C, b.s));
+    void* pb;
+    TRY(b.arena->alloc(&pb, (size_t)4 * C * sizeof(float)));
+    t->in_bias = (float*)pb;
+    HIP_TRY(hipMemcpyAsync(t->in_bias, t->proj_in.bias, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, b.s));
+    HIP_TRY(hipMemcpyAsync(t->in_bias + C, t->qkv.bias, (size_t)3 * C * sizeof(float), hipMemcpyDeviceToDevice, b.s));
+  }
   return 0;
 }
 
@@ -678,12 +689,24 @@ int run_transformer(Exec& ex, const TransformerW& t, const Act& x, Act* out) {
   const int C = t.C, N = x.H * x.W, M = ex.B * N;
   Act n, h, qkv, att, ff;
   TRY(ex.groupnorm(t.norm, x, nullptr, 1e-6f, 0, &n));
-  TRY(ex.conv(t.proj_in, n, nullptr, &h, 1, 0, false, nullptr, 0, nullptr));
-  // norm1 is folded into the q|k|v GEMM: one statistics pass over h (mean, rstd per token), the GEMM reads h itself
-  float* stats = (float*)ws->scratch((size_t)M * 2 * sizeof(float));
-  TRY(ex.rowstats(h, 1e-5f, stats));
-  qkv = ex.new_act(3 * C, x.H, x.W, false);
-  {
+  if (t.in_stream && proj_qkv_fused_ok(C, M, ex.dt)) {
+    // 320-channel level: proj_in -> norm1 -> q|k|v in one row-local launch (tproj.hip): h is written once and not read back
+    h = ex.new_act(C, x.H, x.W, false);
+    qkv = ex.new_act(3 * C, x.H, x.W, false);
+    const double flops = 2.0 * M * 4.0 * C * C;
+    const double bytes = (double)M * C * esize(ex.dt) * 5.0 + (double)proj_qkv_stream_bytes(C);
+    ProfScope ps(0, ex.s, flops, bytes, ex.dry(), "M=" + std::to_string(M) + " proj_ln_qkv C=" + std::to_string(C));
+    if (!ex.dry()) {
+      TRY(ex.ws_ok());
+      const int r = launch_proj_qkv_fused(n.p, h.p, qkv.p, t.in_stream, t.in_bias, igemm_zero_page(), M, C, 1e-5f, ex.s);
+      if (r) return fail(r == -2 ? LDMSEG_E_SHAPE : LDMSEG_E_HIP, "launch_proj_qkv_fused failed");
+    }
+  } else {
+    TRY(ex.conv(t.proj_in, n, nullptr, &h, 1, 0, false, nullptr, 0, nullptr));
+    // norm1 is folded into the q|k|v GEMM: one statistics pass over h (mean, rstd per token), the GEMM reads h itself
+    float* stats = (float*)ws->scratch((size_t)M * 2 * sizeof(float));
+    TRY(ex.rowstats(h, 1e-5f, stats));
+    qkv = ex.new_act(3 * C, x.H, x.W, false);
     IgemmParams p;
     p.src0 = h.p; p.C0 = C; p.B = ex.B; p.Hi = p.Ho = x.H; p.Wi = p.Wo = x.W;
     p.M = M; p.N = t.qkv.N; p.n_valid = 3 * C; p.W = t.qkv.w; p.bias = t.qkv.bias;
@@ -735,6 +758,7 @@ int run_transformer(Exec& ex, const TransformerW& t, const Act& x, Act* out) {
     ws->reset(m);
     return 0;
   }
+  float* stats = (float*)ws->scratch((size_t)M * 2 * sizeof(float));
   TRY(ex.rowstats(h, 1e-5f, stats));          // norm3, folded into the GEGLU GEMM the same way
   ff = ex.new_act(4 * C, x.H, x.W, false);
   {
@@ -1722,6 +1746,7 @@ int ldmseg_debug_set(int key, int value) {
   if (key == 12) { mlp_fused_set_mode(value); ++g_plan_epoch; return 0; }
   if (key == 13) { mlp_fused_set_dbg(value); return 0; }
   if (key == 14) { step_tail_set_mode(value); return 0; }
+  if (key == 16) { proj_qkv_set_mode(value); ++g_plan_epoch; return 0; }   // proj_in -> norm1 -> q|k|v in one launch (bf16, 320 channels); default 1
   if (key == 15) { attention_mx_set_mode(value); ++g_plan_epoch; return 0; }   // fp8 attention: 1 = scaled MFMAs where the shape allows (default), 0 = unscaled   // bit 0: dedicated conv_out kernel (bf16); bit 1: scheduler step in its epilogue   // bit 8: no start-chunk rotation (bits 0-7: ablate builds)   // transformer feed-forward fusion: bit 0 MLP, bit 1 + proj_out
   if (key == 6 || key == 7) { ops_bench_knob(key, value); return 0; }   // ldmseg_bench_igemm: 6 = weight copies rotated, 7 = folded-LN launch   // bits 0-7 ablation flags (LDMSEG_IGEMM_ABLATE builds), bits 8-12 tile policy
   static unsigned long long ts_ptr = 0;                // keys 3/4: low/high half of a device stamp buffer (ablate builds)
@@ -1736,6 +1761,7 @@ int ldmseg_debug_get(int key) {
   if (key == 9) return igemm_get_cm_mode();
   if (key == 12) return mlp_fused_get_mode();
   if (key == 14) return step_tail_get_mode();
+  if (key == 16) return proj_qkv_get_mode();
   if (key == 15) return attention_mx_get_mode();
   if (key == 10) { const long long n = gn_coop_fallbacks(nullptr); return n > 0x7fffffffll ? 0x7fffffff : (int)n; }   // ring regions (ldmseg_op_* launches)
   return 0;

@@ -167,6 +167,15 @@ int mlp_fused_get_mode();
 size_t mlp_fused_stream_bytes(int C);
 // w1: packed GEGLU weights [8C][C] (16-row value | gate interleave, gamma folded in), w2: [C][4C], wp: proj_out [C][C]; bf16
 int launch_pack_mlp_stream(const void* w1, const void* w2, const void* wp, void* out, int C, hipStream_t s);
+// tproj.hip (bf16, C = 320): proj_in -> LayerNorm_1 -> q|k|v of a transformer in one row-local launch (writes h and q|k|v).
+// proj_qkv_fused_ok: the shape / dtype has the kernel and the mode (debug key 16) allows it.
+bool proj_qkv_fused_ok(int C, int M, int dtype);
+void proj_qkv_set_mode(int m);
+int proj_qkv_get_mode();
+size_t proj_qkv_stream_bytes(int C);
+int launch_pack_proj_qkv_stream(const void* wp, const void* wqkv, void* out, int C, hipStream_t s);
+int launch_proj_qkv_fused(const void* x, void* h, void* qkv, const void* stream, const float* bias4, const void* zeros, int M, int C, float eps,
+                          hipStream_t s);
 int launch_mlp_fused(const void* h, void* out, const void* x2, const void* stream, const float* bias1, const float* bias2,
                      const float* bias3, const void* zeros, int M, int C, float eps, int proj, int rows_per_image, hipStream_t s);
 void mlp_fused_set_dbg(int flags);          // bit 8: no start-chunk rotation; bits 0-7: phase ablation (LDMSEG_TFUSE_ABLATE builds only)

@@ -630,6 +630,80 @@ int ldmseg_op_transformer_ff(const float* h, const float* x, const float* gamma,
   return 0;
 }
 
+// The entry of a transformer on caller-supplied weights: h = x Wp^T + bp (proj_in as a Linear on [M][C] rows), q|k|v = [Wq | Wk | Wv]
+// LayerNorm(h; gamma, beta).  mode 0: the unfused launches (GEMM, row statistics, folded-LayerNorm GEMM); 1: the row-local fused
+// kernel (tproj.hip; bf16, C = 320, M % 128 == 0).  Outputs fp32 h [M][C], qkv [M][3C].  time_iters > 0 also times the path.
+int ldmseg_op_transformer_in(const float* x, const float* wp, const float* bp, const float* gamma, const float* beta, const float* wq,
+                             const float* wk, const float* wv, int M, int C, float eps, int dtype, int mode, float* h_out, float* qkv_out,
+                             int time_iters, float* us_per_call, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  Temp t;
+  if (C % bke(dtype) || (mode != 0 && (dtype != DT_BF16 || !proj_qkv_stream_bytes(C) || M % 128))) return -2;
+  void* xp = t.get((size_t)M * C * es(dtype));
+  void* hp = t.get((size_t)M * C * es(dtype));
+  void* qp = t.get((size_t)M * 3 * C * es(dtype));
+  to_dev_dtype(x, xp, (size_t)M * C, dtype, s);
+  std::vector<int> ident(C);
+  for (int r = 0; r < C; ++r) ident[r] = r;
+  int* dident = (int*)t.get(C * sizeof(int));
+  (void)hipMemcpy(dident, ident.data(), C * sizeof(int), hipMemcpyHostToDevice);
+  void* wpp = t.get((size_t)C * C * es(dtype));
+  to_dev_dtype(wp, wpp, (size_t)C * C, dtype, s);
+  void* wqkv = t.get((size_t)3 * C * C * es(dtype));
+  void* wb = t.get((size_t)3 * C * C * sizeof(float));
+  const float* ws3[3] = {wq, wk, wv};
+  for (int i = 0; i < 3; ++i) {
+    if (launch_repack_rows_scaled(ws3[i], (char*)wqkv + (size_t)i * C * C * es(dtype), dident, C, C, gamma, dtype, s)) return -3;
+    if (launch_repack_rows_scaled(ws3[i], (char*)wb + (size_t)i * C * C * sizeof(float), dident, C, C, beta, DT_F32, s)) return -3;
+  }
+  float* bias4 = (float*)t.get((size_t)4 * C * sizeof(float));
+  float* c1 = (float*)t.get((size_t)3 * C * sizeof(float));
+  (void)hipMemcpyAsync(bias4, bp, C * sizeof(float), hipMemcpyDeviceToDevice, s);
+  if (launch_rowsum(wqkv, nullptr, c1, 3 * C, C, dtype, s)) return -3;
+  if (launch_rowsum(wb, nullptr, bias4 + C, 3 * C, C, DT_F32, s)) return -3;
+  void* stream_w = nullptr;
+  if (mode != 0) {
+    stream_w = t.get(proj_qkv_stream_bytes(C));
+    if (launch_pack_proj_qkv_stream(wpp, wqkv, stream_w, C, s)) return -3;
+  }
+  float* stats = (float*)t.get((size_t)M * 2 * sizeof(float));
+  if (igemm_warm()) return -3;
+  auto gemm = [&](const void* src, const void* W, int N, const float* bias, void* o, const float* rs, const float* cc1) -> int {
+    IgemmParams p;
+    p.src0 = src; p.C0 = C; p.B = 1; p.Hi = p.Ho = M; p.Wi = p.Wo = 1;
+    p.M = M; p.N = N; p.n_valid = N; p.W = W; p.bias = bias; p.rowstats = rs; p.c1 = cc1;
+    p.out = o; p.ldo = N; p.epi = EPI_STORE;
+    const int sp = igemm_plan_splits(p, dtype);
+    if (sp > 1) { p.splits = sp; p.partial = (float*)t.get((size_t)sp * M * N * sizeof(float)); }
+    return launch_igemm(p, dtype, s);
+  };
+  auto run = [&]() -> int {
+    if (mode == 0) {
+      if (int r = gemm(xp, wpp, C, bias4, hp, nullptr, nullptr)) return r;
+      if (int r = launch_rowstats(hp, stats, M, C, eps, dtype, s)) return r;
+      return gemm(hp, wqkv, 3 * C, bias4 + C, qp, stats, c1);
+    }
+    return launch_proj_qkv_fused(xp, hp, qp, stream_w, bias4, igemm_zero_page(), M, C, eps, s);
+  };
+  if (int r = run()) return r;
+  if (time_iters > 0 && us_per_call) {
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    for (int i = 0; i < 2; ++i) (void)run();
+    (void)hipEventRecord(e0, s);
+    for (int i = 0; i < time_iters; ++i) (void)run();
+    (void)hipEventRecord(e1, s);
+    (void)hipEventSynchronize(e1);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    *us_per_call = 1e3f * ms / time_iters;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  }
+  from_dev_dtype(hp, h_out, (size_t)M * C, dtype, s);
+  from_dev_dtype(qp, qkv_out, (size_t)M * 3 * C, dtype, s);
+  return 0;
+}
+
 // The step tail kernel (tail.hip, bf16): eps = conv2d(x, w, bias, padding=1) with 320 -> 4 channels on [B,320,H,W] and, when
 // ddim != 0, the scheduler update of `latents` (in place; last != 0: pred_original_sample), the inpainting paste, the
 // self-condition write and the next step's packed input (returned as fp32 [B, H*W, 64]).  eps_out / cond / xin_out / known

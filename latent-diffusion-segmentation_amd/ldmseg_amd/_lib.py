@@ -93,6 +93,7 @@ SIGNATURES = {
     "ldmseg_op_conv_out_tail": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, C.POINTER(C.c_float), _i, _i, _f, _vp, _vp, _vp, _vp, _vp,
                                      _vp, _f, _f, _vp, _vp]),
     "ldmseg_op_transformer_ff": (_i, [_vp] * 10 + [_i, _i, _f, _i, _i, _vp, _i, C.POINTER(C.c_float), _vp]),
+    "ldmseg_op_transformer_in": (_i, [_vp] * 8 + [_i, _i, _f, _i, _i, _vp, _vp, _i, C.POINTER(C.c_float), _vp]),
     "ldmseg_bench_igemm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
                                 C.POINTER(C.c_float), _vp]),
     "ldmseg_bench_attention": (_i, [_vp, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_float), _vp]),

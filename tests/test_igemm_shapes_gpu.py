@@ -28,6 +28,7 @@ SEEN = {(c, dt): set() for c in CONFIGS for dt in (F32, BF16)}
 def L():
     from ldmseg_amd import _lib
     assert _lib.lib().ldmseg_debug_get(1) == _lib.lib().ldmseg_debug_get(-1), "a previous test leaked a tile policy"
+    assert _lib.lib().ldmseg_debug_get(12) == 3 and _lib.lib().ldmseg_debug_get(14) == 3, "a previous test leaked a fused-kernel switch"
     return _lib
 
 
@@ -224,6 +225,21 @@ def test_fused_feed_forward_at_config_shape(L, cfg):
         l2 = float((out.double() - ref.double()).norm() / ref.double().norm())
         assert torch.isfinite(out).all() and l2 < 6e-3 and rel_err(out, ref) < 3e-2, (cfg, mode, l2)
         SEEN[(cfg, BF16)].add(name)
+
+
+@pytest.mark.parametrize("cfg", CONFIGS, ids=CFG_IDS)
+def test_fused_transformer_entry_at_config_shape(L, cfg):
+    """The row-local fused entry kernel (tproj.hip: proj_in -> LayerNorm_1 -> q|k|v) that the bf16 forward runs on the
+    320-channel level, at this configuration's token count, against torch on the same bf16-rounded operands."""
+    from test_ops_gpu import _tin_case, _tin_ref, _tin_run
+    B, lat = cfg
+    M = B * lat * lat
+    case = _tin_case(M, 320, 11 + M)
+    href, qref = _tin_ref(*case)
+    h, qkv, _ = _tin_run(L, case, M, 320, 1)
+    l2 = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    assert torch.isfinite(qkv).all() and l2(h, href) < 3e-3 and l2(qkv, qref) < 6e-3, (cfg, l2(h, href), l2(qkv, qref))
+    SEEN[(cfg, BF16)].add("proj_ln_qkv<bf16>")
 
 
 @pytest.mark.parametrize("mode,dt", [("bf16", BF16), ("fp32", F32)])

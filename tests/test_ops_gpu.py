@@ -860,6 +860,70 @@ def test_transformer_ff_fused_large_mean_rows(L):
         assert float((o.double() - ref.double()).norm() / ref.double().norm()) < 1.5e-2, m
 
 
+# ------------------------------------------------------------------ row-local fused transformer entry (tproj.hip)
+def _tin_case(M, Cc, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(M, Cc, generator=g)
+    wp = torch.randn(Cc, Cc, generator=g) / Cc ** 0.5
+    bp = 0.5 * torch.randn(Cc, generator=g) + 0.4            # rows of h get a mean for the LayerNorm to remove
+    gamma = 1 + 0.2 * torch.randn(Cc, generator=g)
+    beta = 0.2 * torch.randn(Cc, generator=g)
+    wq, wk, wv = (torch.randn(Cc, Cc, generator=g) / Cc ** 0.5 for _ in range(3))
+    return x, wp, bp, gamma, beta, wq, wk, wv
+
+
+def _tin_ref(x, wp, bp, gamma, beta, wq, wk, wv, eps=1e-5):
+    """torch fp32 on the bf16-rounded operands: proj_in, LayerNorm_1, to_q | to_k | to_v (oracle/unet.py::transformer)."""
+    h = F.linear(bf16_round(x), bf16_round(wp), bp)
+    n = F.layer_norm(bf16_round(h), (x.shape[1],), gamma, beta, eps)     # (both paths keep h in bf16)
+    return h, torch.cat([F.linear(n, w) for w in (wq, wk, wv)], dim=-1)
+
+
+def _tin_run(L, case, M, Cc, mode, dt=BF16, iters=0):
+    h = torch.empty(M, Cc, device="cuda")
+    qkv = torch.empty(M, 3 * Cc, device="cuda")
+    keep = [dev(t) for t in case]
+    us = C.c_float(0)
+    r = L.lib().ldmseg_op_transformer_in(*[P(t) for t in keep], M, Cc, 1e-5, dt, mode, P(h), P(qkv), iters, C.byref(us), None)
+    assert r == 0, (r, L.lib().ldmseg_last_error())
+    torch.cuda.synchronize()
+    return h.cpu(), qkv.cpu(), us.value
+
+
+@pytest.mark.parametrize("M", [128, 1024, 4096, 32768])
+def test_transformer_in_fused_vs_torch_and_unfused(L, M):
+    """proj_in -> LayerNorm_1 -> q|k|v of the 320-channel transformers in ONE launch (mode 1) against torch on the same
+    bf16-rounded operands and against the unfused launches (mode 0: GEMM, row statistics, folded-LayerNorm GEMM): one tile
+    up to the configs[1] size (M = 8 x 64 x 64).  h must agree to bf16 rounding (same products, fp32 accumulation in a
+    different order); q|k|v is a bf16-level comparison (the fused kernel rounds the normalised tile to bf16, the unfused
+    path folds the norm into the GEMM epilogue)."""
+    Cc = 320
+    case = _tin_case(M, Cc, 2000 + M)
+    href, qref = _tin_ref(*case)
+    l2 = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    outs = {m: _tin_run(L, case, M, Cc, m) for m in (0, 1)}
+    for m, (h, qkv, _) in outs.items():
+        assert torch.isfinite(h).all() and torch.isfinite(qkv).all(), m
+        assert rel_err(h, href) < 1e-2 and l2(h, href) < 3e-3, (M, m, rel_err(h, href), l2(h, href))
+        assert rel_err(qkv, qref) < 3e-2 and l2(qkv, qref) < 6e-3, (M, m, rel_err(qkv, qref), l2(qkv, qref))
+    assert l2(outs[1][0], outs[0][0]) < 3e-3 and l2(outs[1][1], outs[0][1]) < 6e-3
+    again = _tin_run(L, case, M, Cc, 1)
+    assert torch.equal(again[0], outs[1][0]) and torch.equal(again[1], outs[1][1])      # deterministic
+
+
+def test_transformer_in_fused_rejects_what_it_does_not_cover(L):
+    """Ragged row counts, other channel counts and fp32 are not the fused kernel's: the operator says so (the engine routes
+    such shapes to the unfused launches)."""
+    case = _tin_case(192, 320, 1)
+    h = torch.empty(192, 320, device="cuda")
+    qkv = torch.empty(192, 960, device="cuda")
+    keep = [dev(t) for t in case]
+    us = C.c_float(0)
+    assert L.lib().ldmseg_op_transformer_in(*[P(t) for t in keep], 192, 320, 1e-5, BF16, 1, P(h), P(qkv), 0, C.byref(us), None) != 0
+    assert L.lib().ldmseg_op_transformer_in(*[P(t) for t in keep], 128, 320, 1e-5, F32, 1, P(h), P(qkv), 0, C.byref(us), None) != 0
+    assert L.lib().ldmseg_op_transformer_in(*[P(t) for t in keep], 192, 320, 1e-5, BF16, 0, P(h), P(qkv), 0, C.byref(us), None) == 0
+
+
 # ------------------------------------------------------------------ step tail (tail.hip): conv_out + DDIM + paste + pack
 @pytest.mark.parametrize("case", [
     # B, H, W, pred_type, clip, last, self-condition, inpainting

@@ -26,6 +26,7 @@ python tools/yardstick.py --out $O/yardstick.txt > $O/yardstick.log 2>&1
 python tools/ff_bench.py 32768 65536 > $O/ff_bench.txt 2>&1
 python tools/attn8_bench.py > $O/attn8_bench.txt 2>&1; python tools/attn8_bench.py 4 4096 320 >> $O/attn8_bench.txt 2>&1
 python tools/attn8_acc.py 2>&1 | grep "N=" > $O/attn8_acc.txt
+python tools/attn4_bench.py 2>&1 | grep -v amdgpu.ids > $O/attn4_bench.txt
 python tools/ab_forward.py "12=0,14=0" "12=3,14=0" "12=3,14=1" --rounds 3 > $O/ab_knobs.txt 2>&1
 [ -f scratch/lib_r03.so ] && { LDMSEG_HIP_LIB=scratch/lib_r03.so python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras --no-images --no-torch-reference --profile-steps 0 > $O/bench_r03_lib_same_box.json 2>/dev/null; }
 python tools/kbench.py gn > $O/kbench_groupnorm.txt 2>&1
