@@ -408,16 +408,26 @@ __global__ __launch_bounds__(768, 3) void mlp_fused_kernel(const MlpFusedParams 
       for (int i = 0; i < NI; ++i) rcur[i] = rnext[i];
     }
   } else {
+    // (`zero` is opaque to the optimiser: every lane-dependent address of this branch is derived from it, so none of them is computed
+    // in front of the chunk loop and kept alive through it - that cost the 4 VGPRs by which this variant exceeded its 168-register
+    // budget, i.e. an accumulator fragment parked in scratch and reloaded, with a vmcnt(0) wait, in every chunk)
+    int zero;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
+    const int elane = lane + zero;
+    const int elg = elane >> 4, elq = elane & 15;
+    const int efr_row = elq * 128;
+    const int efr_c0 = ((elg) ^ (elane & 7)) * 16, efr_c1 = ((elg + 4) ^ (elane & 7)) * 16;
+    const int enl = wn * 80 + elg * 4;
     // ---- h_new = acc2 + b2 + h as bf16 back into the tile area (it is proj_out's X operand), then
     //      out = h_new . Wp^T + bp + x2 on the same wave tiles (acc2's registers are reused)
 #pragma unroll
     for (int a = 0; a < 5; ++a) {
-      const int n = nl + a * 16;
+      const int n = enl + a * 16;
       const f32x4 b2 = *(const f32x4*)(p.bias2 + n);
       const int kt = n >> 6, ch = (n & 63) >> 3, half = (n >> 2) & 1;
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
-        const int row = wm * 64 + b * 16 + lq;
+        const int row = wm * 64 + b * 16 + elq;
         const int m = m0 + row;
         uint2 rr = make_uint2(0u, 0u);
         if (m < p.M) rr = *(const uint2*)(p.x + (size_t)m * kC + n);
@@ -440,7 +450,7 @@ __global__ __launch_bounds__(768, 3) void mlp_fused_kernel(const MlpFusedParams 
       for (int a = 0; a < 5; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc3[h][a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const unsigned char* prow = XT + (pm * 32) * 128 + fr_row;
+    const unsigned char* prow = XT + (pm * 32) * 128 + efr_row;
 #pragma unroll 1
     for (int kt = 0; kt < kKT; ++kt) {
       const unsigned char* xs = prow + kt * (kBM * 128);
@@ -448,13 +458,13 @@ __global__ __launch_bounds__(768, 3) void mlp_fused_kernel(const MlpFusedParams 
       for (int h = 0; h < 2; ++h) {
 #pragma unroll
         for (int kg = 0; kg < 2; ++kg) {
-          const int co = kg ? fr_c1 : fr_c0;
+          const int co = kg ? efr_c1 : efr_c0;
           uint4 xf[2], wf[5];
 #pragma unroll
           for (int b = 0; b < 2; ++b) xf[b] = *(const uint4*)(xs + b * 2048 + co);
 #pragma unroll
           for (int a = 0; a < 5; ++a)
-            wf[a] = *(const uint4*)(RING + ((uoff + (unsigned)(pn * 80 + a * 16) * 128u) & (unsigned)(kRing - 1)) + fr_row + co);
+            wf[a] = *(const uint4*)(RING + ((uoff + (unsigned)(pn * 80 + a * 16) * 128u) & (unsigned)(kRing - 1)) + efr_row + co);
 #pragma unroll
           for (int a = 0; a < 5; ++a)
 #pragma unroll
@@ -473,7 +483,7 @@ __global__ __launch_bounds__(768, 3) void mlp_fused_kernel(const MlpFusedParams 
     auto load_res = [&](int blk, uint4 (&r)[NI]) __attribute__((always_inline)) {   // blk = h * 2 + b
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
-        const int cidx = lane + i * 64;
+        const int cidx = elane + i * 64;
         const int row = cidx / CPR, cc = cidx - row * CPR;
         const int m = m0 + pm * 32 + (blk & 1) * 16 + row;
         if (cidx < NCH && m < p.M) r[i] = *(const uint4*)(p.x2 + (size_t)m * kC + (blk >> 1) * 160 + pn * 80 + cc * 8);
@@ -484,17 +494,17 @@ __global__ __launch_bounds__(768, 3) void mlp_fused_kernel(const MlpFusedParams 
     for (int h = 0; h < 2; ++h) {
       f32x4 b3[5];
 #pragma unroll
-      for (int a = 0; a < 5; ++a) b3[a] = *(const f32x4*)(p.bias3 + h * 160 + pn * 80 + a * 16 + lg * 4);
+      for (int a = 0; a < 5; ++a) b3[a] = *(const f32x4*)(p.bias3 + h * 160 + pn * 80 + a * 16 + elg * 4);
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
         const int blk = h * 2 + b;
 #pragma unroll
-        for (int a = 0; a < 5; ++a) *(f32x4*)(stg + lq * SROW + (a * 16 + lg * 4) * 4) = acc3[h][a][b] + b3[a];
+        for (int a = 0; a < 5; ++a) *(f32x4*)(stg + elq * SROW + (a * 16 + elg * 4) * 4) = acc3[h][a][b] + b3[a];
         if (blk + 1 < 4) load_res(blk + 1, rnext);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-          const int cidx = lane + i * 64;
+          const int cidx = elane + i * 64;
           if (cidx < NCH) {
             const int row = cidx / CPR, cc = cidx - row * CPR;
             const int m = m0 + pm * 32 + b * 16 + row;

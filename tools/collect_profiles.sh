@@ -13,7 +13,7 @@ rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -- $BENCH3 > $O/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE -d $O/pmc_mfma -- $BENCH3 > $O/pmc_mfma.log 2>&1
 for d in pmc_fetch pmc_write pmc_mfma; do
   python $R/tools/pmc_query.py $O/$d igemm_kernel > $O/$d.txt 2>&1
-  for k in mlp_fused_kernel conv_out_tail_kernel attn3_kernel attn4_kernel; do python $R/tools/pmc_query.py $O/$d $k >> $O/$d.txt 2>&1; done
+  for k in mlp_fused_kernel proj_ln_qkv_kernel conv_out_tail_kernel attn3_kernel attn4_kernel; do python $R/tools/pmc_query.py $O/$d $k >> $O/$d.txt 2>&1; done
 done
 cd $R
 bash tools/trace_layers.sh bf16 8; cp gpurun_out/trace_layers.txt $O/trace_layers_b8_l64_bf16.txt; cp gpurun_out/layers.csv $O/per_launch_events.csv
@@ -24,10 +24,11 @@ python bench.py --batch 4 --latent 128 --steps 20 --warmup 2 --attention-fp8 163
 # round 4: same-box comparisons
 python tools/yardstick.py --out $O/yardstick.txt > $O/yardstick.log 2>&1
 python tools/ff_bench.py 32768 65536 > $O/ff_bench.txt 2>&1
+python tools/tin_bench.py 32768 65536 2>&1 | grep -v amdgpu.ids > $O/tin_bench.txt
 python tools/attn8_bench.py > $O/attn8_bench.txt 2>&1; python tools/attn8_bench.py 4 4096 320 >> $O/attn8_bench.txt 2>&1
 python tools/attn8_acc.py 2>&1 | grep "N=" > $O/attn8_acc.txt
 python tools/attn4_bench.py 2>&1 | grep -v amdgpu.ids > $O/attn4_bench.txt
-python tools/ab_forward.py "12=0,14=0" "12=3,14=0" "12=3,14=1" --rounds 3 > $O/ab_knobs.txt 2>&1
+python tools/ab_forward.py "12=0,14=0,16=0,2=7" "12=3,14=0,16=0,2=7" "12=3,14=1,16=0,2=7" "12=3,14=1,16=3,2=7" "12=3,14=1,16=3,2=0" --rounds 3 > $O/ab_knobs.txt 2>&1
 [ -f scratch/lib_r03.so ] && { LDMSEG_HIP_LIB=scratch/lib_r03.so python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras --no-images --no-torch-reference --profile-steps 0 > $O/bench_r03_lib_same_box.json 2>/dev/null; }
 python tools/kbench.py gn > $O/kbench_groupnorm.txt 2>&1
 python tools/kbench.py attn > $O/kbench_attention.txt 2>&1

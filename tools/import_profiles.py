@@ -32,7 +32,7 @@ cp("bench_config4_b4_l128_bf16.json", "bench_config4_b4_l128_bf16.json")
 cp("bench_config4_b4_l128_fp8attn.json", "bench_config4_b4_l128_fp8attn.json")
 cp("kbench_groupnorm.txt", "kbench_groupnorm.txt")
 cp("kbench_attention.txt", "kbench_attention.txt")
-for n in ("yardstick.txt", "ff_bench.txt", "attn8_bench.txt", "attn8_acc.txt", "attn4_bench.txt", "ab_forward_vs_r03.txt", "bench_r03_lib_same_box.json", "ab_knobs.txt"):
+for n in ("yardstick.txt", "ff_bench.txt", "tin_bench.txt", "attn8_bench.txt", "attn8_acc.txt", "attn4_bench.txt", "ab_forward_vs_r03.txt", "bench_r03_lib_same_box.json", "ab_knobs.txt"):
     cp(n, n)
 
 
@@ -54,15 +54,15 @@ def per_dispatch(path, counter, kernel):
 
 
 try:
-    n_f, kib_f = per_dispatch(os.path.join(dst, f"{tag}_pmc_fetch.txt"), "FETCH_SIZE", "igemm_kernel|mlp_fused_kernel|conv_out_tail_kernel")
-    n_w, kib_w = per_dispatch(os.path.join(dst, f"{tag}_pmc_write.txt"), "WRITE_SIZE", "igemm_kernel|mlp_fused_kernel|conv_out_tail_kernel")
+    n_f, kib_f = per_dispatch(os.path.join(dst, f"{tag}_pmc_fetch.txt"), "FETCH_SIZE", "igemm_kernel|mlp_fused_kernel|proj_ln_qkv_kernel|conv_out_tail_kernel")
+    n_w, kib_w = per_dispatch(os.path.join(dst, f"{tag}_pmc_write.txt"), "WRITE_SIZE", "igemm_kernel|mlp_fused_kernel|proj_ln_qkv_kernel|conv_out_tail_kernel")
     import bench
     # the hash of the sources the passes ran on = the one the collection's own bench line reports (the local tree may have moved on)
     try:
         sha = json.loads(open(os.path.join(dst, f"{tag}_bench_default.json")).read().strip().splitlines()[-1])["roofline"]["csrc_sha"]
     except Exception:  # noqa: BLE001
         sha = bench.csrc_hash()
-    out = {"kernel": "igemm_kernel (all instantiations) + mlp_fused_kernel + conv_out_tail_kernel", "launches": n_f,
+    out = {"kernel": "igemm_kernel (all instantiations) + mlp_fused_kernel + proj_ln_qkv_kernel + conv_out_tail_kernel", "launches": n_f,
            "fetch_bytes_per_launch": 2 * 1024 * kib_f / n_f, "write_bytes_per_launch": 1024 * kib_w / n_w,
            "hbm_bytes_per_launch": 2 * 1024 * kib_f / n_f + 1024 * kib_w / n_w, "csrc_sha": sha,
            "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 3 --warmup 1 "

@@ -6,7 +6,7 @@ trace, layers = sys.argv[1], sys.argv[2]
 NF = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 rows = list(csv.DictReader(open(trace)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-FAM0 = ("igemm_kernel", "mlp_fused_kernel", "conv_out_tail_kernel")      # the launches ldmseg_profile_dump labels as family 0, in order
+FAM0 = ("igemm_kernel", "mlp_fused_kernel", "proj_ln_qkv_kernel", "conv_out_tail_kernel")      # the launches ldmseg_profile_dump labels as family 0, in order
 ig = [r for r in rows if any(k in r["Kernel_Name"] for k in FAM0)]
 lab = [ln.split(",") for ln in open(layers).read().splitlines()[1:]]
 lab0 = [l for l in lab if l[0] == "0"]
@@ -24,7 +24,7 @@ for f in range(2, NF):                              # skip the first two forward
         a[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3; a[2] += float(l[3])
 n = NF - 2
 tot = sum(a[1] for a in agg.values()) / n; fl = sum(a[2] for a in agg.values()) / n
-print(f"GEMM-family kernels (igemm + fused feed-forward + conv_out tail): {per_fwd} launches/forward, {tot:.1f} us/forward, {fl/tot/1e6:.1f} TFLOP/s")
+print(f"GEMM-family kernels (igemm + fused transformer kernels + conv_out tail): {per_fwd} launches/forward, {tot:.1f} us/forward, {fl/tot/1e6:.1f} TFLOP/s")
 oth = collections.Counter(); 
 t0 = int(ig[2 * per_fwd]["Start_Timestamp"])
 for r in rows:

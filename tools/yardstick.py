@@ -86,6 +86,34 @@ def torch_gemm_us(M, N, K, taps, stride, up, epi, B, L):
     return ev_time(run)
 
 
+def torch_fused_us(kind, M, C=320):
+    """torch-ROCm bf16 time of what one fused row-local launch covers: 'ff' = LayerNorm -> GEGLU -> ff.net.2 (+h) -> proj_out (+x),
+    'in' = proj_in -> LayerNorm -> q|k|v (three Linears as one [3C, C] GEMM)."""
+    dev, dt = "cuda", torch.bfloat16
+    h, x = torch.randn(M, C, device=dev, dtype=dt), torch.randn(M, C, device=dev, dtype=dt)
+    g, b = torch.ones(C, device=dev, dtype=dt), torch.zeros(C, device=dev, dtype=dt)
+    n = 8
+    if kind == "ff":
+        w1 = [torch.randn(8 * C, C, device=dev, dtype=dt) * 0.02 for _ in range(n)]
+        w2 = [torch.randn(C, 4 * C, device=dev, dtype=dt) * 0.02 for _ in range(n)]
+        wp = [torch.randn(C, C, device=dev, dtype=dt) * 0.02 for _ in range(n)]
+        b1, b2 = torch.randn(8 * C, device=dev, dtype=dt), torch.randn(C, device=dev, dtype=dt)
+
+        def run(i):
+            a, gate = F.linear(F.layer_norm(h, (C,), g, b), w1[i % n], b1).chunk(2, dim=-1)
+            h2 = F.linear(a * F.gelu(gate), w2[i % n], b2) + h
+            return F.linear(h2, wp[i % n], b2) + x
+        return ev_time(run)
+    wp = [torch.randn(C, C, device=dev, dtype=dt) * 0.02 for _ in range(n)]
+    wq = [torch.randn(3 * C, C, device=dev, dtype=dt) * 0.02 for _ in range(n)]
+    bp = torch.randn(C, device=dev, dtype=dt)
+
+    def run(i):
+        hh = F.linear(x, wp[i % n], bp)
+        return hh, F.linear(F.layer_norm(hh, (C,), g, b), wq[i % n])
+    return ev_time(run)
+
+
 def torch_attn_us(B, N, C):
     d = C // 8
     q, k, v = (torch.randn(B, 8, N, d, device="cuda", dtype=torch.bfloat16) for _ in range(3))
@@ -165,6 +193,10 @@ def main():
                 M, N, K, taps, stride, up, epi = map(int, m.groups())
                 if epi in (0, 1) and N >= 32:
                     tt = torch_gemm_us(M, N, K, taps, stride, up, epi, B, L)
+            else:
+                m = re.match(r"M=(\d+) (mlp_fused|proj_ln_qkv) C=(\d+)", label)
+                if m:
+                    tt = torch_fused_us("ff" if m.group(2) == "mlp_fused" else "in", int(m.group(1)), int(m.group(3)))
         elif fam == 1:
             m = re.match(r"N=(\d+) C=(\d+)", label)
             if m:
