@@ -20,4 +20,4 @@ for name, key in (("scaled, 4 waves, plain", 0x101), ("scaled, 8 waves, plain", 
 L.ldmseg_debug_set(15, 0x111)
 us = C.c_float(0)
 assert L.ldmseg_bench_attention(P(qkv), B, N, Cc, 8, 1, 10, C.byref(us), None) == 0
-print(f"{'bf16 (attention3)':30s} B={B} N={N} C={Cc}: {us.value:9.1f} us  ({fl / us.value / 1e6:7.1f} TF/s)")
+print(f"{'bf16 (shipped rule: attention4)':30s} B={B} N={N} C={Cc}: {us.value:9.1f} us  ({fl / us.value / 1e6:7.1f} TF/s)")
