@@ -280,9 +280,12 @@ int ldmseg_profile_dump(const char* path);
  * (bit 0: dedicated conv_out kernel in bf16, bit 1: the sampling loop's scheduler step / self-condition / next-input pack in
  * its epilogue; default 3); key 15 = fp8 attention on the block-scaled 2x-rate MFMAs where the shape allows (head dim 40,
  * tokens a multiple of 128; default 1, 0 = the unscaled fp8 MFMAs of attention_fp8.hip; 0x111 = scaled MFMAs with exp +
- * convert instead of the direct e4m3 byte - attention_mx.hip). */
+ * convert instead of the direct e4m3 byte - attention_mx.hip); key 16 = row-local fusion of the 320-channel transformer entry
+ * (proj_in -> LayerNorm_1 -> q|k|v in one launch, tproj.hip; bit 0 on, bit 1 loader block rotation; default 3, 0 = the unfused
+ * launches); key 2 values: 0 = shipped rule, 7 = the round-3 rule (attention3.hip at head dim 40), 11..14 = attention4.hip forced
+ * (8 / 4 waves, lazily tracked / every-tile maxima). */
 int ldmseg_debug_set(int key, int value);
-/* current value of a knob (key 1); key -1 = the shipped default of key 1.  Tests restore through this, never a literal.
+/* current value of a knob (keys 1, 9, 12, 14, 15, 16); key -1 = the shipped default of key 1.  Tests restore through this, never a literal.
  * key 10 = number of cooperative-GroupNorm workgroups that took the self-computing path in ldmseg_op_* launches so far. */
 int ldmseg_debug_get(int key);
 
