@@ -372,6 +372,43 @@ def test_forward_graph_capture_and_replay(unets):
             assert torch.equal(y_static, ref), rep
 
 
+def test_unet_fused_and_unfused_launch_sets_agree(unets):
+    """Round 4 replaced groups of launches of the bf16 forward by fused kernels (debug keys 12: transformer feed-forward, 14: step
+    tail / conv_out, 16: transformer entry, 2: attention kernel).  Every switch set to its round-3 launches, one at a time and all
+    together, must give the same forward up to bf16 rounding flips - both against the shipped forward and against the fp32
+    parity mode - and the fp32 mode must not move at all (none of the fused kernels serves it)."""
+    from ldmseg_amd import _lib
+    lib = _lib.lib()
+    shipped = {12: lib.ldmseg_debug_get(12), 14: lib.ldmseg_debug_get(14), 16: lib.ldmseg_debug_get(16), 2: 0}
+    assert shipped[12] == 3 and shipped[14] == 3 and shipped[16] == 3
+    x = torch.randn(2, 12, 64, 64, generator=torch.Generator().manual_seed(12)).to(DEV)
+    ref16 = unets["bf16"](x, 500).sample.clone()
+    ref32 = unets["fp32"](x, 500).sample.clone()
+    l2 = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    base = l2(ref16, ref32)
+    old = {12: 0, 14: 0, 16: 0, 2: 7}
+    try:
+        for keys in ([12], [14], [16], [2], [12, 14, 16, 2]):
+            for k in keys:
+                assert lib.ldmseg_debug_set(k, old[k]) == 0
+            y16 = unets["bf16"](x, 500).sample.clone()
+            y32 = unets["fp32"](x, 500).sample.clone()
+            for k in keys:
+                lib.ldmseg_debug_set(k, shipped[k])
+            assert torch.isfinite(y16).all()
+            e, e32 = l2(y16, ref16), l2(y16, ref32)
+            print(f"keys {keys} at their round-3 launches: bf16 vs shipped {e:.2e}, vs fp32 {e32:.2e} (shipped vs fp32 {base:.2e})")
+            assert e < 3e-2 and e32 < 1.5 * base + 1e-3, (keys, e, e32, base)
+            if keys != [14]:
+                assert not torch.equal(y16, ref16), keys        # a different set of kernels really ran
+            else:
+                assert torch.equal(y16, ref16)                    # the tail kernel keeps the implicit GEMM's K order: bit-identical eps
+            assert torch.equal(y32, ref32), keys
+    finally:
+        for k, v in shipped.items():
+            lib.ldmseg_debug_set(k, v)
+
+
 def test_unet_conv_k_order_modes_agree(unets):
     """The 3x3 convs of the 320- / 640-channel levels hold two weight packings ((tap, channel) and (channel tile, tap,
     channel)); a bf16 launch picks by map size.  Forcing either order everywhere must give the same forward up to rounding
