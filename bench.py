@@ -420,7 +420,7 @@ def main():
                 tj = json.load(fh)
             if tj.get("csrc_sha") == csrc_hash():       # stale (kernels changed since the PMC passes) -> null
                 traffic, traffic_src = tj.get("hbm_bytes_per_launch"), "profiles/" + cands[-1]
-        roofline = {"bound": "mfma", "kernel": "igemm_kernel (conv3x3/conv1x1/Linear)", "achieved": ach / 1e12,
+        roofline = {"bound": "mfma", "kernel": "GEMM family: igemm_kernel (conv3x3 / conv1x1 / Linear / GEGLU) + mlp_fused_kernel + proj_ln_qkv_kernel + conv_out_tail_kernel", "achieved": ach / 1e12,
                     "peak": peak / 1e12, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
                     "traffic_unit": "HBM bytes per launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, separate passes)",
                     "traffic_source": traffic_src, "csrc_sha": csrc_hash(),
