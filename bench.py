@@ -2,6 +2,7 @@
 """Benchmark of the LDMSeg denoising path on MI355X.
 
     python bench.py --gpus 1 --steps 50 --warmup 5
+    python bench.py --gpus N --steps K --warmup W          (spawns its own N ranks under torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 Workload (BASELINE.json configs[1], per GPU): 512x512 images -> 64x64x4 latents, batch 8, bf16,
@@ -199,6 +200,29 @@ def kl_encoder_flops(H, W):
     return f
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(n):
+    """Re-run this command line as n ranks under torch.distributed.run (one node, 127.0.0.1 rendezvous) and pass rank 0's
+    JSON line through.  Returns the launcher's exit code."""
+    import subprocess
+    if os.environ.get("LDMSEG_BENCH_BACKEND", "nccl") == "nccl" and torch.cuda.device_count() < n:
+        print(f"--gpus {n} needs {n} visible devices, found {torch.cuda.device_count()} "
+              f"(LDMSEG_BENCH_BACKEND=gloo exercises the control flow with ranks sharing devices)", file=sys.stderr)
+        return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this pool's host driver
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(int(os.environ.get("MASTER_PORT", 0)) or free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -222,9 +246,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` called directly: spawn the ranks ourselves (one process per GPU under
+        # torch.distributed.run, rendezvous on 127.0.0.1) like the reference's entry does with mp.spawn
+        # (tools/main_ldm.py:59-69,108-111).  The explicit-launcher form keeps working: it sets WORLD_SIZE.
+        raise SystemExit(self_launch(args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch {args.gpus} ranks (or call bench.py directly, it spawns them)")
     import torch.distributed as dist
     # LDMSEG_BENCH_BACKEND=gloo lets the multi-rank control flow be exercised on a box with fewer GPUs than ranks
     # (ranks then share devices); the measured configuration is one rank per GPU over RCCL ("nccl")
@@ -456,22 +484,28 @@ def main():
         # BASELINE configs[4]: 1024x1024 -> 128x128x4 latents, batch 4 (N = 16384 tokens in the first attention level)
         r128 = timed(tr, 4, 128, 5)
         r128["whole_step_mfma_frac"] = r128["image_steps_per_s"] * FLOP_UNET[128] / PEAK_BF16
-        r128["attention_path"] = "bf16 (attention3.hip)" if args.dtype == "bf16" else "fp32"
-        extras["config4_1024px_b4_l128_" + args.dtype] = r128
+        r128["attention_path"] = ("bf16: attn4_kernel (attention4.hip) at head dim 40, attn3_kernel (attention3.hip) at head dim 80, "
+                                  "attention_kernel (attention.hip) at head dim 160") if args.dtype == "bf16" else "fp32 (attention.hip)"
+        extras["configs[4]_1024px_b4_l128_" + args.dtype] = r128
         if args.dtype == "bf16":                      # the fp8 MFMA attention path BASELINE configs[4] names
             unet.set_attention_fp8(16384)
             r8 = timed(tr, 4, 128, 5)
             unet.set_attention_fp8(0)
             r8["whole_step_mfma_frac"] = r8["image_steps_per_s"] * FLOP_UNET[128] / PEAK_BF16
-            r8["attention_path"] = "fp8 e4m3 operands on the 16384-token level (attention_fp8.hip), bf16 elsewhere"
-            extras["config4_1024px_b4_l128_fp8_attention"] = r8
+            mx = _lib.lib().ldmseg_debug_get(15)
+            r8["attention_path"] = ("fp8 e4m3 operands on the 16384-token level: "
+                                    + ("attn_mx_kernel on the block-scaled MFMAs (attention_mx.hip), "
+                                       + ("probabilities built directly as e4m3 bytes" if (mx & 0x20) else "exact exp")
+                                       if (mx & 1) else "attn_fp8_kernel on the unscaled fp8 MFMAs (attention_fp8.hip)")
+                                    + "; bf16 kernels on the other levels")
+            extras["configs[4]_1024px_b4_l128_fp8_attention"] = r8
         # BASELINE configs[3]: mask inpainting, batch 16, 50 % of the latents known
         def inpaint(tr_, rgbx, sx):
             gi = torch.Generator().manual_seed(7)
             z0 = (0.2 * torch.randn(rgbx.shape, generator=gi)).to(dev)
             known = (torch.rand(rgbx.shape[0], 1, rgbx.shape[2], rgbx.shape[3], generator=gi) < 0.5).to(dev)
             return tr_.sample_inpaint([""] * rgbx.shape[0], known, z0, seed=42, rgb_latents=rgbx, scheduler=sx)
-        extras["config3_inpaint_b16_l64_" + args.dtype] = timed(tr, 16, 64, 10, inpaint)
+        extras["configs[3]_inpaint_b16_l64_" + args.dtype] = timed(tr, 16, 64, 10, inpaint)
         # fp32 parity mode (the mode the 1e-3 parity claims are made in), same workload as the headline line
         if args.dtype == "bf16":
             unet32 = UNet(usd, in_channels=12, device=dev, compute_dtype="fp32")

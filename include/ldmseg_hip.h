@@ -105,6 +105,11 @@ int ldmseg_unet_set_attention_fp8(ldmseg_unet* h, int min_tokens);
  * self-condition and time-embedding buffers); may synchronise the device.  Optional: without it the first call at a new,
  * larger shape does the same lazily. */
 int ldmseg_unet_reserve(ldmseg_unet* h, int B, int L);
+/* Workgroups of this handle's cooperative GroupNorm launches that did not see their partners within the poll bound and
+ * computed the partners' statistics themselves since the handle was created (0 on an undisturbed device: the kernel's
+ * workgroups are co-resident).  Synchronises.  ldmseg_sample_loop looks at the same counter (asynchronously) and runs the
+ * next calls with a short poll bound while it grows.  No reference counterpart (torch's GroupNorm is one kernel). */
+int ldmseg_unet_gn_fallbacks(ldmseg_unet* h, int64_t* count);
 /* bytes of device workspace a forward at (B, L) needs (allocated lazily, grown never shrunk) */
 size_t ldmseg_unet_workspace_bytes(const ldmseg_unet* h, int B, int L);
 /* number of parameters held (815,556,484 for the 12-channel default) */

@@ -366,7 +366,7 @@ void attention_mx_set_mode(int m) {    // bit 0: on / off; bit 8: variant from b
   g_mx_variant = (m & 0x100) ? ((m >> 4) & 3) : 3;
   g_mx_pshift = (m & 0x200) ? 13.0f + (float)((m >> 16) & 0xfff) * 1e-3f : 13.95f;
 }
-int attention_mx_get_mode() { return g_mx_mode; }
+int attention_mx_get_mode() { return g_mx_mode | (g_mx_variant << 4); }   // bit 0: on; bits 4-5: variant (bit 5 = direct e4m3 byte)
 bool attention_mx_ok(int N, int C, int heads) { return g_mx_mode && heads > 0 && C / heads == kD && N % kTile == 0 && N >= kTile; }
 size_t attention_mx_scratch_bytes(int B, int N, int C, int heads) {
   return attention_mx_ok(N, C, heads) ? (size_t)B * heads * (N / kTile) * (kKB + kVB) : 0;

@@ -280,6 +280,7 @@ struct Exec {
   hipStream_t s;
   int attn_fp8_min_tokens = 0;
   void* gn_sync = nullptr;     // the handle's hand-off region of the cooperative GroupNorm (gn_sync_bytes())
+  int gn_poll_us = -1;         // >= 0: poll bound of this handle's cooperative norms (backing off, see ldmseg_sample_loop)
   bool dry() const { return ws->dry; }
   // a request beyond the planned workspace (a plan made under other tuning knobs): fail before anything is launched on it
   int ws_ok() const { return ws->overflow ? fail(LDMSEG_E_OOM, "workspace plan exceeded (stale plan): nothing was launched") : 0; }
@@ -389,6 +390,7 @@ struct Exec {
     g.out = out->p;
     g.nchunk = gn_nchunk(B, g.HW);
     g.sync_region = gn_sync;
+    g.poll_us = gn_poll_us;
     g.partial = (float*)ws->scratch((size_t)B * g.nchunk * 32 * 2 * sizeof(float));
     const double bytes = 3.0 * B * g.HW * ctot * esize(dt);
     ProfScope ps(2, s, 0, bytes, dry(), "HW=" + std::to_string(g.HW) + " C=" + std::to_string(ctot));
@@ -471,6 +473,14 @@ struct ldmseg_unet {
   // launch carries it out (tail_done) and leaves the next forward's packed input in place (xin_ready)
   const StepTail* tail_req = nullptr;
   bool tail_done = false, xin_ready = false;
+  // Cooperative GroupNorm back-off: the fallback counter of the handle's hand-off region is copied to this
+  // pinned word at the end of every sampling call; a call that finds it has grown since the last look runs its norms with a
+  // 2 us poll bound (partners that are not co-resident - another process or stream holding CUs - then cost the extra reads of
+  // the two-launch scheme instead of a 100 us spin per norm) for the next few calls, then tries the full bound again.
+  unsigned long long* gn_diag_host = nullptr;
+  unsigned long long gn_diag_seen = 0;
+  int gn_backoff_calls = 0;
+  const void* xin_ptr = nullptr;       // where the tail wrote that input: the next forward skips its pack only if its own xin IS this buffer
 
   ~ldmseg_unet() {
     arena.release();
@@ -478,6 +488,7 @@ struct ldmseg_unet {
     if (cond) (void)hipFree(cond);
     if (eps) (void)hipFree(eps);
     if (temb_buf) (void)hipFree(temb_buf);
+    if (gn_diag_host) (void)hipHostFree(gn_diag_host);
     if (gn_sync) (void)hipFree(gn_sync);
   }
 };
@@ -793,6 +804,7 @@ int unet_forward_impl(ldmseg_unet* u, const float* a, int Ca, const float* b, in
   Exec ex{ws, u->dt, B, s};
   ex.attn_fp8_min_tokens = u->attn_fp8_min_tokens;
   ex.gn_sync = u->gn_sync;
+  ex.gn_poll_us = u->gn_backoff_calls > 0 ? 2 : -1;
   const int dt = u->dt;
 
   // --- time embedding: sinusoid -> MLP -> every resnet's time_emb_proj(SiLU(emb)) ---
@@ -820,8 +832,11 @@ int unet_forward_impl(ldmseg_unet* u, const float* a, int Ca, const float* b, in
 
   // --- conv_in on the channel-concatenated fp32 NCHW input ---
   Act xin = ex.new_act(bke(dt), L, L, true);
-  if (!dry && u->xin_ready) {
-    u->xin_ready = false;          // the previous step's tail already wrote [latents | rgb | cond] here (tail.hip)
+  // (a re-plan or a workspace reallocation between two steps moves xin: the pointer the tail wrote to must be this one)
+  const bool xin_kept = !dry && u->xin_ready && u->xin_ptr == xin.p;
+  if (!dry) { u->xin_ready = false; u->xin_ptr = nullptr; }
+  if (xin_kept) {
+    // the previous step's tail already wrote [latents | rgb | cond] here (tail.hip)
   } else {
     ProfScope ps(4, s, 0, 0, dry);
     if (!dry) TRY(ex.ws_ok());
@@ -895,7 +910,7 @@ int unet_forward_impl(ldmseg_unet* u, const float* a, int Ca, const float* b, in
         TRY(ex.ws_ok());
         const int r = launch_conv_out_tail(t, s);
         if (r) return fail(r == -2 ? LDMSEG_E_SHAPE : LDMSEG_E_HIP, "launch_conv_out_tail failed");
-        if (t.ddim) { u->tail_done = true; u->xin_ready = t.xin_next != nullptr; }
+        if (t.ddim) { u->tail_done = true; u->xin_ready = t.xin_next != nullptr; u->xin_ptr = t.xin_next; }
       }
     } else {
       IgemmParams p;
@@ -935,7 +950,12 @@ int unet_forward_checked(ldmseg_unet* u, const float* a, int Ca, const float* b,
     u->plan_L = L;
     u->plan_epoch = g_plan_epoch;
   }
-  TRY(ensure_ws(&u->ws_mem, &u->ws_cap, &u->ws, u->plan_persist + u->plan_scratch));
+  {
+    const void* before = u->ws_mem;
+    const size_t cap_before = u->ws_cap;
+    TRY(ensure_ws(&u->ws_mem, &u->ws_cap, &u->ws, u->plan_persist + u->plan_scratch));
+    if (u->ws_mem != before || u->ws_cap != cap_before) { u->xin_ready = false; u->xin_ptr = nullptr; }   // (a new arena may reuse the old address)
+  }
   return unet_forward_impl(u, a, Ca, b, Cb, c, Cc, t_dev, t_count, t_host, B, L, out, s, false, u->plan_persist);
 }
 
@@ -1640,7 +1660,17 @@ int ldmseg_sample_loop(ldmseg_unet* h, const ldmseg_sample_cfg* cfg, float* late
   if (selfc) HIP_TRY(hipMemsetAsync(h->cond, 0, n * sizeof(float), s));   // condition = zeros_like(rgb_latents)
   const float* temb_rows = nullptr;
   TRY(loop_time_embeddings(h, cfg->timesteps, cfg->n_steps, s, &temb_rows));
-  struct Clear { ldmseg_unet* u; ~Clear() { u->temb_override = nullptr; u->tail_req = nullptr; u->tail_done = false; u->xin_ready = false; } } clear{h};     // (also on the error returns below)
+  if (h->gn_sync) {                  // cooperative GroupNorm back-off: did the previous calls' norms miss their partners?
+    if (!h->gn_diag_host) {
+      HIP_TRY(hipHostMalloc((void**)&h->gn_diag_host, sizeof(unsigned long long)));
+      *h->gn_diag_host = 0;
+    }
+    const unsigned long long cur = *(volatile unsigned long long*)h->gn_diag_host;     // whatever the last finished copy left
+    if (cur >= h->gn_diag_seen + 256) h->gn_backoff_calls = 8;
+    else if (h->gn_backoff_calls > 0) --h->gn_backoff_calls;
+    h->gn_diag_seen = cur;
+  }
+  struct Clear { ldmseg_unet* u; ~Clear() { u->temb_override = nullptr; u->tail_req = nullptr; u->tail_done = false; u->xin_ready = false; u->xin_ptr = nullptr; } } clear{h};     // (also on the error returns below)
   for (int i = 0; i < cfg->n_steps; ++i) {
     h->temb_override = temb_rows + (size_t)i * h->temb_total;
     const float* c = cfg->coef + 4 * i;
@@ -1670,6 +1700,18 @@ int ldmseg_sample_loop(ldmseg_unet* h, const ldmseg_sample_cfg* cfg, float* late
     if (all_latents)
       HIP_TRY(hipMemcpyAsync(all_latents + (size_t)i * n, latents, n * sizeof(float), hipMemcpyDeviceToDevice, s));
   }
+  if (h->gn_sync && h->gn_diag_host)
+    HIP_TRY(hipMemcpyAsync(h->gn_diag_host, gn_sync_diag_ptr(h->gn_sync), sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  return 0;
+}
+
+int ldmseg_unet_gn_fallbacks(ldmseg_unet* h, int64_t* count) {
+  g_err.clear();
+  if (!h || !count) return fail(LDMSEG_E_ARG, "null argument");
+  DeviceGuard dg(h->cfg.device);
+  const long long n = h->gn_sync ? gn_coop_fallbacks(h->gn_sync) : 0;
+  if (n < 0) return fail(LDMSEG_E_HIP, "reading the GroupNorm fallback counter failed");
+  *count = n;
   return 0;
 }
 
@@ -1743,12 +1785,14 @@ int ldmseg_debug_set(int key, int value) {
   static int gn_mode = 0, gn_poll = 100;
   if (key == 10) { gn_mode = value; groupnorm_set_coop(gn_mode, gn_poll); return 0; }
   if (key == 11) { gn_poll = value; groupnorm_set_coop(gn_mode, gn_poll); return 0; }
-  if (key == 12) { mlp_fused_set_mode(value); ++g_plan_epoch; return 0; }
-  if (key == 13) { mlp_fused_set_dbg(value); return 0; }
-  if (key == 14) { step_tail_set_mode(value); return 0; }
+  if (key == 12) { mlp_fused_set_mode(value); ++g_plan_epoch; return 0; }   // transformer feed-forward fusion: bit 0 MLP, bit 1 + proj_out
+  if (key == 13) { mlp_fused_set_dbg(value); return 0; }                    // bit 8: no start-chunk rotation (bits 0-7: ablate builds)
+  // 14: step tail.  bit 0: dedicated conv_out kernel (bf16); bit 1: scheduler step in its epilogue.  (The implicit-GEMM
+  // conv_out it falls back to plans split-K scratch: a new plan epoch.)
+  if (key == 14) { step_tail_set_mode(value); ++g_plan_epoch; return 0; }
   if (key == 16) { proj_qkv_set_mode(value); ++g_plan_epoch; return 0; }   // proj_in -> norm1 -> q|k|v in one launch (bf16, 320 channels); default 1
-  if (key == 15) { attention_mx_set_mode(value); ++g_plan_epoch; return 0; }   // fp8 attention: 1 = scaled MFMAs where the shape allows (default), 0 = unscaled   // bit 0: dedicated conv_out kernel (bf16); bit 1: scheduler step in its epilogue   // bit 8: no start-chunk rotation (bits 0-7: ablate builds)   // transformer feed-forward fusion: bit 0 MLP, bit 1 + proj_out
-  if (key == 6 || key == 7) { ops_bench_knob(key, value); return 0; }   // ldmseg_bench_igemm: 6 = weight copies rotated, 7 = folded-LN launch   // bits 0-7 ablation flags (LDMSEG_IGEMM_ABLATE builds), bits 8-12 tile policy
+  if (key == 15) { attention_mx_set_mode(value); ++g_plan_epoch; return 0; }   // fp8 attention: 1 = scaled MFMAs where the shape allows (default), 0 = unscaled
+  if (key == 6 || key == 7) { ops_bench_knob(key, value); return 0; }   // ldmseg_bench_igemm: 6 = weight copies rotated, 7 = folded-LN launch
   static unsigned long long ts_ptr = 0;                // keys 3/4: low/high half of a device stamp buffer (ablate builds)
   if (key == 3) { ts_ptr = (ts_ptr & 0xffffffff00000000ull) | (unsigned)value; igemm_set_tsbuf((void*)(uintptr_t)ts_ptr); return 0; }
   if (key == 4) { ts_ptr = (ts_ptr & 0xffffffffull) | ((unsigned long long)(unsigned)value << 32); igemm_set_tsbuf((void*)(uintptr_t)ts_ptr); return 0; }

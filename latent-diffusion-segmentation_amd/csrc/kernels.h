@@ -133,6 +133,7 @@ struct GNParams {
   int splits = 1;                                       // workgroups that share one (image, group block)
   int coop_mode = 0;                                    // 1: never poll, always take the self-computing path (tests)
   int poll_ticks = 10000;                               // bound of the partner poll in 100 MHz wall-clock ticks
+  int poll_us = -1;                                     // >= 0: this launch's poll bound instead of the process-wide one (a handle backing off)
 };
 size_t gn_sync_bytes();
 int gn_sync_init(void* region, hipStream_t s);
@@ -141,6 +142,7 @@ int gn_warm();                                          // per-device ring alloc
 void groupnorm_set_coop(int mode, int poll_us);
 // workgroups that took the self-computing path since the region was initialised (region null: sum over the ring of the current device)
 long long gn_coop_fallbacks(const void* region);
+const void* gn_sync_diag_ptr(const void* region);      // device address of a region's 8-byte fallback counter
 int gn_nchunk(int B, int HW);
 int launch_groupnorm(const GNParams& p, int dtype, hipStream_t s);
 // Split-K finish of a conv fused with the GroupNorm (+SiLU) that consumes it (resnet conv1 -> norm2 on the 8x8 / 16x16

@@ -1218,8 +1218,13 @@ void gn_bind_region(GNParams& p, unsigned long long* base) {
 }
 std::mutex g_gn_mu;
 unsigned long long* g_gn_ring[64] = {};
-unsigned g_gn_next[64] = {};
-unsigned long long* gn_ring_region(int* dev_out = nullptr) {
+hipStream_t g_gn_ring_stream[64][kGnRing] = {};
+int g_gn_ring_used[64] = {};
+// One region per (device, stream): launches of one stream are ordered, so consecutive norms draw consecutive generations
+// on their region exactly like a handle's do; two streams never share one (round 4 handed the regions out round-robin,
+// so that two cooperative launches in flight on different streams could meet on one region after the ring wrapped and
+// read each other's records - ADVICE r04).  More distinct streams than regions: null, the caller takes the two-launch path.
+unsigned long long* gn_ring_region(hipStream_t s, int* dev_out = nullptr) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
   if (dev_out) *dev_out = dev;
@@ -1230,7 +1235,15 @@ unsigned long long* gn_ring_region(int* dev_out = nullptr) {
     (void)hipMemset(q, 0, kGnRegionWords * kGnRing * sizeof(unsigned long long));
     g_gn_ring[dev] = (unsigned long long*)q;
   }
-  return g_gn_ring[dev] + (size_t)(g_gn_next[dev]++ % kGnRing) * kGnRegionWords;
+  int idx = -1;
+  for (int i = 0; i < g_gn_ring_used[dev]; ++i)
+    if (g_gn_ring_stream[dev][i] == s) { idx = i; break; }
+  if (idx < 0) {
+    if (g_gn_ring_used[dev] >= kGnRing) return nullptr;
+    idx = g_gn_ring_used[dev]++;
+    g_gn_ring_stream[dev][idx] = s;
+  }
+  return g_gn_ring[dev] + (size_t)idx * kGnRegionWords;
 }
 
 int g_gn_coop_mode = 0;     // 1: every cooperative workgroup computes its partners' records itself (tests of the cold path)
@@ -1269,12 +1282,14 @@ int run_gn(const GNParams& pin, hipStream_t s) {
       if (((p.HW + S - 1) / S + ppi - 1) / ppi > MAXVC) continue;
       if (slabs * S > num_cus_gn()) continue;                     // every workgroup must be resident: one per CU (8 waves at ~200 registers)
       unsigned long long* region = (unsigned long long*)p.sync_region;
-      if (!region) region = gn_ring_region();
-      if (!region) return -3;
+      if (!region) {
+        region = gn_ring_region(s);
+        if (!region) break;                                         // no region for this stream: the two-launch path below
+      }
       gn_bind_region(p, region);
       p.splits = S;
       p.coop_mode = g_gn_coop_mode;
-      p.poll_ticks = g_gn_poll_us * 100;                          // wall_clock64: 100 MHz
+      p.poll_ticks = (p.poll_us >= 0 ? p.poll_us : g_gn_poll_us) * 100;   // wall_clock64: 100 MHz
       p.per = (p.HW + S - 1) / S;
       p.ty = ppi;
       p.fd_aux = fastdiv_make(vpp);
@@ -1453,6 +1468,9 @@ int gn_warm() {
     g_gn_ring[dev] = (unsigned long long*)q;
   }
   return 0;
+}
+const void* gn_sync_diag_ptr(const void* region) {
+  return region ? (const void*)((const unsigned long long*)region + kGnCtrWords + kGnRecWords) : nullptr;
 }
 long long gn_coop_fallbacks(const void* region) {
   unsigned long long v = 0, tot = 0;

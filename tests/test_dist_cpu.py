@@ -66,3 +66,21 @@ def test_sharded_sampling_gloo(mode):
     expect = torch.tanh(noise + 3.0 * rgb) * 7
     assert torch.equal(res[0], res[1])            # every rank holds the gathered batch
     assert torch.equal(res[0], expect)
+
+
+def test_bench_direct_form_spawns_ranks_that_refuse_without_a_gpu():
+    """`python bench.py --gpus 2` with no launcher re-executes itself under torch.distributed.run.  Here
+    (no GPU) the spawned ranks must refuse loudly - there is no CPU fallback - and the RCCL form must refuse before spawning."""
+    import os, subprocess, sys
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("the GPU suite runs the direct form for real (tests/test_bench_gpu.py)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=dict(env, LDMSEG_BENCH_BACKEND="nccl"))
+    assert r.returncode != 0 and "visible devices" in r.stderr
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=dict(env, LDMSEG_BENCH_BACKEND="gloo"))
+    assert r.returncode != 0 and "needs an MI355X" in (r.stderr + r.stdout)       # both ranks started and refused
