@@ -55,6 +55,9 @@ extern "C" {
 
 #define LDMSEG_F32 0           /* fp32 storage, exact-f32 MFMA: the parity mode (1e-3 vs torch-CPU) */
 #define LDMSEG_BF16 1          /* bf16 storage + bf16 MFMA, fp32 accumulate/statistics: the perf mode */
+#define LDMSEG_BF16X3 2        /* fp32 storage, norms / softmax / scheduler in fp32, GEMM products on the bf16 MFMAs as hi + lo
+                                * (three MFMAs per product block, fp32 accumulation; relative error per product < 2^-16):
+                                * the parity-grade throughput mode - inside the 1e-3 bound at several times the exact mode's speed */
 
 #define LDMSEG_PRED_EPSILON 0
 #define LDMSEG_PRED_SAMPLE 1
@@ -68,7 +71,7 @@ typedef struct ldmseg_vae_image ldmseg_vae_image;  /* opaque */
 typedef struct {
   int32_t in_channels;      /* 8 | 12 after UNet.modify_encoder (unet.py:178-233); 4 = vanilla */
   int32_t cross_attention;  /* 0: attn2/norm2 removed (unet.py:83-105, base.yaml:71). 1 is rejected (E_ARG) */
-  int32_t compute_dtype;    /* LDMSEG_F32 | LDMSEG_BF16 */
+  int32_t compute_dtype;    /* LDMSEG_F32 | LDMSEG_BF16 | LDMSEG_BF16X3 */
   int32_t device;           /* HIP device ordinal */
 } ldmseg_unet_cfg;
 
@@ -99,6 +102,8 @@ int ldmseg_unet_forward_parts(ldmseg_unet* h, const float* latents, const float*
 /* bf16 mode only: run the self-attention of every level with at least `min_tokens` tokens (H*W) on the fp8 operand path
  * (OCP e4m3 Q/K/V/P on v_mfma_f32_16x16x32_fp8_fp8, fp32 accumulation and statistics) - the "fp8 MFMA attention path" of
  * the 1024x1024 configuration (128x128 latents: 16384 / 4096 tokens at head dims 40 / 80); 0 switches it off (default).
+ * Levels where the fp8 path is not the faster one (head dim 80 / token counts that are not a multiple of 128: only the unscaled
+ * fp8 MFMAs serve them, at the bf16 rate) stay on the bf16 kernel whatever `min_tokens` says.
  * The reference has no counterpart (its attention is whatever diffusers' processor does in fp32). */
 int ldmseg_unet_set_attention_fp8(ldmseg_unet* h, int min_tokens);
 /* Allocate everything forward / sample_loop need at (B, L) now (workspace + the sampler's eps,
@@ -191,7 +196,7 @@ int64_t ldmseg_vae_num_params(const ldmseg_vae* h);
  * conv_norm_out + SiLU + conv_out 512->8, quant_conv 8->8.  The arithmetic is diffusers' (not vendored by the
  * reference): parity is pinned against oracle/vae_image.py only. */
 typedef struct {
-  int32_t compute_dtype;    /* LDMSEG_F32 | LDMSEG_BF16 */
+  int32_t compute_dtype;    /* LDMSEG_F32 | LDMSEG_BF16 | LDMSEG_BF16X3 */
   int32_t device;
 } ldmseg_vae_image_cfg;
 /* keys: the 'vae_image' entry of ldmseg.pt (trainers_ldm_cond.py:1805) / AutoencoderKL.state_dict():

@@ -193,6 +193,7 @@ struct ConvW {
   float* c1 = nullptr;    // [N] row sums of w when a LayerNorm is folded into this GEMM (IgemmParams::c1), else null
   int N = 0, n_valid = 0, cin_pad = 0, taps = 1, cout = 0;
   void* w_cm = nullptr;   // 3x3 layers that may run on large maps: second packing in channel-major K order (IgemmParams::cm)
+  void* w_ws = nullptr;   // wide layers with long K: third packing, fragment-major (IgemmParams::Wf, igemm_ws.hip) - small maps
 };
 struct NormW { float* g = nullptr; float* b = nullptr; int C = 0; };
 
@@ -241,6 +242,10 @@ struct Builder {
       TRY(arena->alloc(&out->w_cm, (size_t)Npad * k * k * cin_pad * esize(dt)));
       TRY(launch_repack_conv(w, out->w_cm, Co, Ci, k, k, Npad, cin_pad, dt, s, bke(dt)));
     }
+    if (igemm_ws_wants(Npad, k * k * cin_pad, epi, dt)) {
+      TRY(arena->alloc(&out->w_ws, (size_t)Npad * k * k * cin_pad * esize(dt)));
+      TRY(launch_pack_ws(out->w, out->w_ws, Npad, k * k * cin_pad, s));
+    }
     nparams += (int64_t)Co * Ci * k * k;
     if (has_bias) TRY(f32_copy(prefix + ".bias", Co, &out->bias, Npad));
     else {
@@ -281,6 +286,7 @@ struct Exec {
   int attn_fp8_min_tokens = 0;
   void* gn_sync = nullptr;     // the handle's hand-off region of the cooperative GroupNorm (gn_sync_bytes())
   int gn_poll_us = -1;         // >= 0: poll bound of this handle's cooperative norms (backing off, see ldmseg_sample_loop)
+  int x3 = 0;                  // fp32 handles in LDMSEG_BF16X3 mode: IgemmParams::x3 of every GEMM launch
   bool dry() const { return ws->dry; }
   // a request beyond the planned workspace (a plan made under other tuning knobs): fail before anything is launched on it
   int ws_ok() const { return ws->overflow ? fail(LDMSEG_E_OOM, "workspace plan exceeded (stale plan): nothing was launched") : 0; }
@@ -313,6 +319,7 @@ struct Exec {
     ProfScope ps(0, s, flops, bytes, dry(), label);
     if (dry()) return 0;
     TRY(ws_ok());
+    p.x3 = (dt == DT_F32) ? x3 : 0;
     return launch_igemm(p, dt, s);
   }
 
@@ -332,7 +339,7 @@ struct Exec {
     p.B = B; p.Hi = x.H; p.Wi = x.W; p.Ho = Ho; p.Wo = Wo;
     p.taps = w.taps; p.stride = stride; p.up = up; p.pad = pad;
     p.M = B * Ho * Wo; p.N = w.N; p.n_valid = w.n_valid;
-    p.W = w.w; p.bias = w.bias;
+    p.W = w.w; p.bias = w.bias; p.Wf = w.w_ws;
     if (w.w_cm && pad < 0 && igemm_conv_cm(x.H * x.W, ctot, w.N, 3, stride, up, dt)) { p.W = w.w_cm; p.cm = 1; }
     p.rowbias = rowbias; p.rb_stride = rb_stride;
     if (resid) { p.resid = resid->p; p.ldr = resid->C; }
@@ -352,7 +359,7 @@ struct Exec {
     p.B = B; p.Hi = x.H; p.Wi = x.W; p.Ho = x.H; p.Wo = x.W;
     p.taps = w.taps; p.stride = 1; p.up = 0; p.pad = -1;
     p.M = B * x.H * x.W; p.N = w.N; p.n_valid = w.n_valid;
-    p.W = w.w; p.bias = w.bias;
+    p.W = w.w; p.bias = w.bias; p.Wf = w.w_ws;
     p.rowbias = rowbias; p.rb_stride = rb_stride;
     p.epi = EPI_STORE;
     const int sp = igemm_plan_splits(p, dt);
@@ -442,6 +449,7 @@ struct TransformerW {
 struct ldmseg_unet {
   ldmseg_unet_cfg cfg{};
   int dt = DT_BF16;
+  bool x3 = false;      // fp32 storage with split-bf16 GEMM arithmetic (LDMSEG_BF16X3)
   DeviceArena arena;
   Workspace ws;
   void* ws_mem = nullptr;
@@ -730,7 +738,10 @@ int run_transformer(Exec& ex, const TransformerW& t, const Act& x, Act* out) {
     const double d = C / 8.0;
     ProfScope ps(1, ex.s, 4.0 * ex.B * 8 * (double)N * N * d, 4.0 * M * C * esize(ex.dt), ex.dry(),
                  "N=" + std::to_string(N) + " C=" + std::to_string(C));
-    const size_t kv8 = (ex.dt == DT_BF16 && ex.attn_fp8_min_tokens > 0 && N >= ex.attn_fp8_min_tokens)
+    // (only where the fp8 path is the faster one: head dim 40 on whole 128-key tiles = the block-scaled 2x-rate MFMAs.  The
+    // unscaled fp8 kernel that would serve head dim 80 / ragged lengths runs at the bf16 MFMA rate and measured SLOWER than the
+    // bf16 kernel - 222 vs 205 us at d = 80, N = 4096 - so a handle asked for fp8 from 4096 tokens up keeps that level in bf16)
+    const size_t kv8 = (ex.dt == DT_BF16 && ex.attn_fp8_min_tokens > 0 && N >= ex.attn_fp8_min_tokens && attention_mx_ok(N, C, 8))
                            ? attention_fp8_scratch_bytes(ex.B, N, C, 8) : 0;
     if (kv8) {                                     // long-context level on the fp8 operand path (BASELINE configs[4])
       void* scratch = ws->scratch(kv8);
@@ -804,6 +815,7 @@ int unet_forward_impl(ldmseg_unet* u, const float* a, int Ca, const float* b, in
   Exec ex{ws, u->dt, B, s};
   ex.attn_fp8_min_tokens = u->attn_fp8_min_tokens;
   ex.gn_sync = u->gn_sync;
+  ex.x3 = u->x3 ? 1 : 0;
   ex.gn_poll_us = u->gn_backoff_calls > 0 ? 2 : -1;
   const int dt = u->dt;
 
@@ -979,6 +991,7 @@ int make_weight_map(int n, const char* const* names, const void* const* ptrs, co
 struct ldmseg_vae {
   ldmseg_vae_cfg cfg{};
   int dt = DT_BF16;
+  bool x3 = false;      // fp32 storage with split-bf16 GEMM arithmetic (LDMSEG_BF16X3)
   DeviceArena arena;
   Workspace ws;
   void* ws_mem = nullptr;
@@ -1073,6 +1086,7 @@ int vae_decode_impl(ldmseg_vae* v, const float* z, float z_scale, int B, int L, 
   ws->begin(dry, scratch_base);
   Exec ex{ws, v->dt, B, s};
   ex.gn_sync = v->gn_sync;
+  ex.x3 = v->x3 ? 1 : 0;
   const int dt = v->dt;
   const ldmseg_vae_cfg& c = v->cfg;
   Act zin = ex.new_act(bke(dt), L, L, true);
@@ -1140,6 +1154,7 @@ int vae_encode_impl(ldmseg_vae* v, const float* x, float mul, float add, int B, 
   ws->begin(dry, scratch_base);
   Exec ex{ws, v->dt, B, s};
   ex.gn_sync = v->gn_sync;
+  ex.x3 = v->x3 ? 1 : 0;
   const int dt = v->dt;
   const ldmseg_vae_cfg& c = v->cfg;
   Act xin = ex.new_act(bke(dt), H, H, true);
@@ -1172,6 +1187,7 @@ int vae_encode_impl(ldmseg_vae* v, const float* x, float mul, float add, int B, 
 struct ldmseg_vae_image {
   ldmseg_vae_image_cfg cfg{};
   int dt = DT_BF16;
+  bool x3 = false;      // fp32 storage with split-bf16 GEMM arithmetic (LDMSEG_BF16X3)
   DeviceArena arena;
   Workspace ws;
   void* ws_mem = nullptr;
@@ -1309,6 +1325,7 @@ int klenc_encode_impl(ldmseg_vae_image* v, const float* x, float mul, float add,
   ws->begin(dry, scratch_base);
   Exec ex{ws, v->dt, B, s};
   ex.gn_sync = v->gn_sync;
+  ex.x3 = v->x3 ? 1 : 0;
   const int dt = v->dt;
   Act xin = ex.new_act(bke(dt), H, W, true);
   {
@@ -1348,7 +1365,7 @@ int ldmseg_unet_create(const ldmseg_unet_cfg* cfg, int n_weights, const char* co
   g_err.clear();
   if (!cfg || !out) return fail(LDMSEG_E_ARG, "null argument");
   if (cfg->cross_attention) return fail(LDMSEG_E_ARG, "cross-attention (encoder_hidden_states) is not supported: the reference default removes it (base.yaml:71)");
-  if (cfg->compute_dtype != LDMSEG_F32 && cfg->compute_dtype != LDMSEG_BF16) return fail(LDMSEG_E_ARG, "bad compute_dtype");
+  if (cfg->compute_dtype != LDMSEG_F32 && cfg->compute_dtype != LDMSEG_BF16 && cfg->compute_dtype != LDMSEG_BF16X3) return fail(LDMSEG_E_ARG, "bad compute_dtype");
   if (cfg->in_channels != 4 && cfg->in_channels != 8 && cfg->in_channels != 12) return fail(LDMSEG_E_ARG, "in_channels must be 4, 8 or 12");
   DeviceGuard dg(cfg->device);
   TRY(check_arch(cfg->device));
@@ -1357,6 +1374,7 @@ int ldmseg_unet_create(const ldmseg_unet_cfg* cfg, int n_weights, const char* co
   ldmseg_unet* u = new ldmseg_unet();
   u->cfg = *cfg;
   u->dt = cfg->compute_dtype == LDMSEG_BF16 ? DT_BF16 : DT_F32;
+  u->x3 = cfg->compute_dtype == LDMSEG_BF16X3;
   int r = unet_build(u, wm);
   if (r == 0) r = igemm_warm();
   if (r == 0) r = alloc_gn_sync(&u->gn_sync);
@@ -1400,7 +1418,7 @@ int ldmseg_vae_create(const ldmseg_vae_cfg* cfg, int n_weights, const char* cons
                       const int64_t* numels, ldmseg_vae** out) {
   g_err.clear();
   if (!cfg || !out) return fail(LDMSEG_E_ARG, "null argument");
-  if (cfg->compute_dtype != LDMSEG_F32 && cfg->compute_dtype != LDMSEG_BF16) return fail(LDMSEG_E_ARG, "bad compute_dtype");
+  if (cfg->compute_dtype != LDMSEG_F32 && cfg->compute_dtype != LDMSEG_BF16 && cfg->compute_dtype != LDMSEG_BF16X3) return fail(LDMSEG_E_ARG, "bad compute_dtype");
   if (cfg->num_latents != 2 || cfg->norm_num_groups != 32) return fail(LDMSEG_E_ARG, "only the gaussian parametrization with 32 groups is supported");
   DeviceGuard dg(cfg->device);
   TRY(check_arch(cfg->device));
@@ -1409,6 +1427,7 @@ int ldmseg_vae_create(const ldmseg_vae_cfg* cfg, int n_weights, const char* cons
   ldmseg_vae* v = new ldmseg_vae();
   v->cfg = *cfg;
   v->dt = cfg->compute_dtype == LDMSEG_BF16 ? DT_BF16 : DT_F32;
+  v->x3 = cfg->compute_dtype == LDMSEG_BF16X3;
   int r = vae_build(v, wm);
   if (r == 0) r = igemm_warm();
   if (r == 0) r = alloc_gn_sync(&v->gn_sync);
@@ -1484,7 +1503,7 @@ int ldmseg_vae_image_create(const ldmseg_vae_image_cfg* cfg, int n_weights, cons
                             const void* const* dev_ptrs, const int64_t* numels, ldmseg_vae_image** out) {
   g_err.clear();
   if (!cfg || !out) return fail(LDMSEG_E_ARG, "null argument");
-  if (cfg->compute_dtype != LDMSEG_F32 && cfg->compute_dtype != LDMSEG_BF16) return fail(LDMSEG_E_ARG, "bad compute_dtype");
+  if (cfg->compute_dtype != LDMSEG_F32 && cfg->compute_dtype != LDMSEG_BF16 && cfg->compute_dtype != LDMSEG_BF16X3) return fail(LDMSEG_E_ARG, "bad compute_dtype");
   DeviceGuard dg(cfg->device);
   TRY(check_arch(cfg->device));
   WeightMap wm;
@@ -1492,6 +1511,7 @@ int ldmseg_vae_image_create(const ldmseg_vae_image_cfg* cfg, int n_weights, cons
   ldmseg_vae_image* v = new ldmseg_vae_image();
   v->cfg = *cfg;
   v->dt = cfg->compute_dtype == LDMSEG_BF16 ? DT_BF16 : DT_F32;
+  v->x3 = cfg->compute_dtype == LDMSEG_BF16X3;
   int r = klenc_build(v, wm);
   if (r == 0) r = igemm_warm();
   if (r == 0) r = alloc_gn_sync(&v->gn_sync);
@@ -1792,6 +1812,10 @@ int ldmseg_debug_set(int key, int value) {
   if (key == 14) { step_tail_set_mode(value); ++g_plan_epoch; return 0; }
   if (key == 16) { proj_qkv_set_mode(value); ++g_plan_epoch; return 0; }   // proj_in -> norm1 -> q|k|v in one launch (bf16, 320 channels); default 1
   if (key == 15) { attention_mx_set_mode(value); ++g_plan_epoch; return 0; }   // fp8 attention: 1 = scaled MFMAs where the shape allows (default), 0 = unscaled
+  // 17: weight-streaming kernel of the small maps (igemm_ws.hip).  bits 0-2: mode (bit 0 on, bit 1 4-wave workgroups, bit 2 whole-k-group X buffers + 3-slot ring),
+  // bits 8-19: largest M it takes (0: keep), bits 20-27: fewest K tiles (0: keep).  Default 1 | M <= 1024 | >= 40 K tiles
+  if (key == 17) { igemm_ws_set_mode(value & 7, (value >> 8) & 0xfff ? ((value >> 8) & 0xfff) * 4 : 0, (value >> 20) & 0xff); ++g_plan_epoch; return 0; }
+  if (key == 18) { igemm_set_wt(value); return 0; }       // experiment: write-through (sc1) row-major epilogue stores of igemm_kernel
   if (key == 6 || key == 7) { ops_bench_knob(key, value); return 0; }   // ldmseg_bench_igemm: 6 = weight copies rotated, 7 = folded-LN launch
   static unsigned long long ts_ptr = 0;                // keys 3/4: low/high half of a device stamp buffer (ablate builds)
   if (key == 3) { ts_ptr = (ts_ptr & 0xffffffff00000000ull) | (unsigned)value; igemm_set_tsbuf((void*)(uintptr_t)ts_ptr); return 0; }
@@ -1807,6 +1831,8 @@ int ldmseg_debug_get(int key) {
   if (key == 14) return step_tail_get_mode();
   if (key == 16) return proj_qkv_get_mode();
   if (key == 15) return attention_mx_get_mode();
+  if (key == 17) return igemm_ws_get_mode();
+  if (key == 18) return igemm_get_wt();
   if (key == 10) { const long long n = gn_coop_fallbacks(nullptr); return n > 0x7fffffffll ? 0x7fffffff : (int)n; }   // ring regions (ldmseg_op_* launches)
   return 0;
 }

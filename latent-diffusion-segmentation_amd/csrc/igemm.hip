@@ -69,6 +69,12 @@ __device__ __forceinline__ void glds16_sbase(unsigned voff, const void* sbase, u
       : "memory");
 }
 
+// 16-byte store that writes through to the device-coherent level (sc1) instead of leaving a dirty line in the XCD's L2
+__device__ __forceinline__ void store16_wt(void* dst, const uint4& v) {
+  const u32x4 d = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dst), "v"(d) : "memory");
+}
+
 struct RowInfo {
   int pix_base;  // b * Hi * Wi
   int iy0, ix0;  // top-left input coordinate (logical, before upsample shift)
@@ -78,6 +84,10 @@ struct RowInfo {
 // -DLDMSEG_IGEMM_ABLATE: every one of them is a branch in code that runs cold once per launch.
 #ifdef LDMSEG_IGEMM_ABLATE
 #define DBG(p, bit) ((p).dbg & (bit))
+#define STAMP(p, slot)                                                                              \
+  if ((p).ts && threadIdx.x == 0) (p).ts[(size_t)blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memtime();
+#elif defined(LDMSEG_IGEMM_STAMP)     // stamps only (no phase-skipping branches: the 12-wave tiles keep their register allocation)
+#define DBG(p, bit) 0
 #define STAMP(p, slot)                                                                              \
   if ((p).ts && threadIdx.x == 0) (p).ts[(size_t)blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memtime();
 #else
@@ -489,8 +499,10 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LDR) * 64, (WAVES_M * WAVES_N 
 #pragma unroll
               for (int e = 0; e < E; ++e) v[e] = silu_f(v[e]);
             }
-            if (!DBG(p, 64)) *(uint4*)((T*)p.out + (size_t)m * p.ldo + n) = Chunk<T>::pack(v);
-            else asm volatile("" ::"v"(v[0]), "v"(v[E - 1]));
+            if (!DBG(p, 64)) {
+              if (p.wt) store16_wt((T*)p.out + (size_t)m * p.ldo + n, Chunk<T>::pack(v));
+              else *(uint4*)((T*)p.out + (size_t)m * p.ldo + n) = Chunk<T>::pack(v);
+            } else asm volatile("" ::"v"(v[0]), "v"(v[E - 1]));
           }
         }
       }
@@ -586,8 +598,10 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LDR) * 64, (WAVES_M * WAVES_N 
                 const f32x4 t = *(const f32x4*)(sp + q * 16);
                 v[q * 4 + 0] = t[0]; v[q * 4 + 1] = t[1]; v[q * 4 + 2] = t[2]; v[q * 4 + 3] = t[3];
               }
-              if (!DBG(p, 64)) *(uint4*)((T*)p.out + (size_t)m * p.ldo + oc0 + cc * E) = Chunk<T>::pack(v);
-              else asm volatile("" ::"v"(v[0]), "v"(v[E - 1]));
+              if (!DBG(p, 64)) {
+                if (p.wt) store16_wt((T*)p.out + (size_t)m * p.ldo + oc0 + cc * E, Chunk<T>::pack(v));
+                else *(uint4*)((T*)p.out + (size_t)m * p.ldo + oc0 + cc * E) = Chunk<T>::pack(v);
+              } else asm volatile("" ::"v"(v[0]), "v"(v[E - 1]));
             }
           }
         }
@@ -838,8 +852,56 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LDR) * 64, (WAVES_M * WAVES_N 
       const bool more = DBG(p, 1) ? false : fetch_next(fst);
       const unsigned char* xs = smem + cur * kStageBytes + (wm * WTM) * kRowBytes + fr_row;
       const unsigned char* ws = smem + cur * kStageBytes + (BM + wn * WTN) * kRowBytes + fr_row;
+      bool x3_done = false;
+      if constexpr (sizeof(T) == 4) {
+        // Split-bf16 arithmetic on fp32 operands (IgemmParams::x3, compute_dtype "bf16x3"): every fp32 value is hi + lo with
+        // hi = bf16(x) and lo = bf16(x - hi) (x - hi is exact in fp32), and X.W ~ Wl.Xh + Wh.Xl + Wh.Xh on v_mfma_f32_16x16x32_bf16
+        // with fp32 accumulation - the dropped Wl.Xl term and the rounding of lo are below 2^-16 relative per product.  One
+        // K tile (32 floats per row) is exactly one K = 32 MFMA step: a lane's two 16-byte chunks (k = 4 lg .. and 16 + 4 lg ..)
+        // are its eight contraction elements, the same lane -> k map for both operands.  3 MFMAs of 16 cycles per 32 k
+        // instead of 8 v_mfma_f32_16x16x4_f32 of 32 cycles: 5.3 x the matrix rate of the exact fp32 path; ~24 VALU
+        // instructions per fragment for the split.
+        if (p.x3) {
+          x3_done = true;
+          auto split = [&](const uint4& c0, const uint4& c1, uint4& hi, uint4& lo) __attribute__((always_inline)) {
+            const float f[8] = {bits_f32(c0.x), bits_f32(c0.y), bits_f32(c0.z), bits_f32(c0.w),
+                                bits_f32(c1.x), bits_f32(c1.y), bits_f32(c1.z), bits_f32(c1.w)};
+            unsigned h[4], l[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              h[i] = pack_bf16x2(f[2 * i], f[2 * i + 1]);
+              const float r0 = f[2 * i] - bits_f32(h[i] << 16), r1 = f[2 * i + 1] - bits_f32(h[i] & 0xffff0000u);
+              l[i] = pack_bf16x2(r0, r1);
+            }
+            hi = make_uint4(h[0], h[1], h[2], h[3]);
+            lo = make_uint4(l[0], l[1], l[2], l[3]);
+          };
+          // X fragments are split once per tile and kept (MF x 8 registers); W fragments go through one at a time (the 64 x 80
+          // wave tiles have 80 accumulator registers: holding every split fragment at once spilled 60-90 VGPRs)
+          uint4 xh[MF], xl[MF];
+#pragma unroll
+          for (int b = 0; b < MF; ++b)
+            split(*(const uint4*)(xs + b * 16 * kRowBytes + fr_c0), *(const uint4*)(xs + b * 16 * kRowBytes + fr_c1), xh[b], xl[b]);
+#pragma unroll
+          for (int a = 0; a < NF; ++a) {
+            uint4 wh, wl;
+            split(*(const uint4*)(ws + a * 16 * kRowBytes + fr_c0), *(const uint4*)(ws + a * 16 * kRowBytes + fr_c1), wh, wl);
+            // small terms first; consecutive MFMAs go to different accumulators
+#pragma unroll
+            for (int b = 0; b < MF; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wl), __builtin_bit_cast(bf16x8, xh[b]), acc[a][b], 0, 0, 0);
+#pragma unroll
+            for (int b = 0; b < MF; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wh), __builtin_bit_cast(bf16x8, xl[b]), acc[a][b], 0, 0, 0);
+#pragma unroll
+            for (int b = 0; b < MF; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wh), __builtin_bit_cast(bf16x8, xh[b]), acc[a][b], 0, 0, 0);
+          }
+        }
+      }
 #pragma unroll
       for (int kg = 0; kg < 2; ++kg) {
+        if (x3_done) break;
         if (DBG(p, 8)) break;          // ablation: no LDS reads, no MFMA
         const int co = kg ? fr_c1 : fr_c0;
         uint4 wf[NF], xf[MF];
@@ -977,6 +1039,7 @@ int g_big = kDefaultPolicy;      // bit0: 8-wave 256-row tiles with a 3-stage ri
                      // bit2: lone 64-row 4-stage tiles; bit3: pipelined K loop on the 256-row tiles; bit4: 8-wave 128-row
                      // tiles (+ loader waves on long K); bit5: loader waves on the 256-row tiles (long K / GEGLU)
 
+int g_wt = 0;                    // igemm_set_wt
 int g_force_cfg = -1;            // tools/tune_igemm.py: run every launch with this entry of the instantiation list
 int g_cm_mode = -1;              // igemm_set_cm_mode
 
@@ -1002,6 +1065,7 @@ template <typename T, int BM, int BN, int WM, int WN, int NST = 2, bool PIPE = f
 int run(const IgemmParams& pin, hipStream_t s) {
   IgemmParams p = pin;
   p.dbg = g_dbg;
+  p.wt = g_wt;
   p.ts = (unsigned long long*)g_tsbuf;
   p.zeros = zero_page();
   if (!p.zeros) return -3;
@@ -1110,8 +1174,32 @@ int dispatch_ln(const IgemmParams& p, hipStream_t s) {
   return geglu ? run<T, 64, 128, 2, 2, 2, false, 0, true>(p, s) : run<T, 64, 160, 2, 2, 2, false, 0, true>(p, s);
 }
 
+// the split-K finish every kernel of the family shares (p.splits > 1, slabs written)
+template <typename T>
+int launch_finish(const IgemmParams& pin, hipStream_t s) {
+  IgemmParams p = pin;
+  p.fd_hwo = fastdiv_make(p.Ho * p.Wo);
+  const int nq = p.n_valid >> 2;
+  const int gx = (nq + 63) / 64;
+  int gy = (p.M + 3) / 4;
+  if (gy > 2048 / gx) gy = 2048 / gx > 0 ? 2048 / gx : 1;
+  hipLaunchKernelGGL(splitk_finish_kernel<T>, dim3(gx, gy), dim3(256), 0, s, p);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
 template <typename T>
 int dispatch(const IgemmParams& p, hipStream_t s) {
+  if constexpr (sizeof(T) == 2) {
+    // small maps, long K: the weight-streaming kernel (igemm_ws.hip) writes the slabs
+    if (p.splits > 1 && g_big == kDefaultPolicy && g_force_cfg < 0 && igemm_ws_ok(p, DT_BF16)) {
+      const int r = launch_igemm_ws(p, s);
+      if (r) return r;
+      const int nw = igemm_ws_waves();
+      g_last = IgemmDispatch{DT_BF16, 128, 32 * nw, 1, nw, 4, 1, 0, p.splits, ((p.M + 127) / 128) * (p.N / (32 * nw)) * p.splits, 0, 0, nw};
+      if (g_log_on) g_log.insert(igemm_dispatch_name(g_last));
+      return p.no_finish ? 0 : launch_finish<T>(p, s);
+    }
+  }
   if (p.cm) {   // channel-major 3x3 conv: one instantiation (the 256-row loader-wave tile the large maps use anyway), bf16 only
     if constexpr (sizeof(T) == 2) {
       if (!p.rowstats && p.epi == EPI_STORE && p.N % 160 == 0) return run<T, 256, 160, 4, 2, 3, true, 4, false, true>(p, s);
@@ -1120,12 +1208,35 @@ int dispatch(const IgemmParams& p, hipStream_t s) {
   }
   {
     int cfg = g_force_cfg;
-    if (cfg < 0) {
+    if (cfg < 0 && !p.x3) {
       if (const TunedEntry* e = tuned_lookup(p, sizeof(T) == 2 ? DT_BF16 : DT_F32)) cfg = e->cfg;
     }
-    if (cfg >= 0) {
+    if (cfg >= 0 && !p.x3) {
       const int r = run_cfg_any<T>(cfg, p, s);
       if (r != -2 || g_force_cfg >= 0) return r;     // a forced entry that does not exist for this launch is an error
+    }
+  }
+  if constexpr (sizeof(T) == 4) {
+    // split-bf16 mode: the arithmetic lives in the plain K loop only, so these launches take the plain-loop instantiations
+    if (p.x3) {
+      // Tile choice: fp32 operands double the bytes staged per MAC, so these launches are bound by the L2 -> LDS path before the
+      // split's VALU work: the largest tile wins even where its 64 x 80 wave tiles spill 17-19 VGPRs in this loop (measured:
+      // 36.8 ms per B = 8 / L = 64 forward with the large tiles against 41.0 ms with spill-free 64-row tiles)
+      const int bnx = (p.epi == EPI_GEGLU) ? 128 : (p.N % 160 == 0 ? 160 : (p.N % 128 == 0 ? 128 : (p.N % 64 == 0 ? 64 : 32)));
+      const int sp = p.splits > 1 ? p.splits : 1;
+      const long t256 = (long)((p.M + 255) / 256) * (p.N / bnx) * sp, t128 = (long)((p.M + 127) / 128) * (p.N / bnx) * sp;
+      const long t64 = (long)((p.M + 63) / 64) * (p.N / bnx) * sp;
+      if (bnx == 64) return run<T, 128, 64, 4, 1>(p, s);
+      if (bnx == 32) return run<T, 128, 32, 4, 1>(p, s);
+      if (p.rowstats) {
+        if (t128 >= 400) return bnx == 160 ? run<T, 128, 160, 2, 2, 2, false, 0, true>(p, s) : run<T, 128, 128, 2, 2, 2, false, 0, true>(p, s);
+        if (t64 <= num_cus()) return bnx == 160 ? run<T, 64, 160, 2, 2, 4, false, 0, true>(p, s) : run<T, 64, 128, 2, 2, 4, false, 0, true>(p, s);
+        return bnx == 160 ? run<T, 64, 160, 2, 2, 2, false, 0, true>(p, s) : run<T, 64, 128, 2, 2, 2, false, 0, true>(p, s);
+      }
+      if (t256 >= 240) return bnx == 160 ? run<T, 256, 160, 4, 2, 3, false>(p, s) : run<T, 256, 128, 4, 2, 3, false>(p, s);
+      if (t128 >= 400) return bnx == 160 ? run<T, 128, 160, 2, 2>(p, s) : run<T, 128, 128, 2, 2>(p, s);
+      if (t64 <= num_cus()) return bnx == 160 ? run<T, 64, 160, 2, 2, 4>(p, s) : run<T, 64, 128, 2, 2, 4>(p, s);
+      return bnx == 160 ? run<T, 64, 160, 2, 2>(p, s) : run<T, 64, 128, 2, 2>(p, s);
     }
   }
   if (p.rowstats) return dispatch_ln<T>(p, s);
@@ -1182,6 +1293,8 @@ int igemm_warm() { return zero_page() ? 0 : -3; }
 const void* igemm_zero_page() { return zero_page(); }
 void igemm_set_tsbuf(void* b) { g_tsbuf = b; }
 void igemm_force_cfg(int cfg) { g_force_cfg = cfg; }
+void igemm_set_wt(int on) { g_wt = on ? 1 : 0; }
+int igemm_get_wt() { return g_wt; }
 void igemm_set_dbg(int f) { g_dbg = f & 0xff; g_big = (f >> 8) & 63; }   // bits 8-13 select the tile policy
 int igemm_get_dbg() { return (g_big << 8) | g_dbg; }
 int igemm_default_dbg() { return kDefaultPolicy << 8; }
@@ -1189,6 +1302,10 @@ IgemmDispatch igemm_last_dispatch() { return g_last; }
 // "igemm<dtype,BM,BN,WM,WN,NST,PIPE,LDR>" + "/splitk" when the launch ran K slices (partial epilogue + finish kernel)
 std::string igemm_dispatch_name(const IgemmDispatch& d) {
   char buf[96];
+  if (d.ws) {
+    std::snprintf(buf, sizeof buf, "igemm_ws<bf16,%d,%d,w%d>/splitk", d.bm, d.bn, d.ws);
+    return buf;
+  }
   std::snprintf(buf, sizeof buf, "igemm<%s,%d,%d,%d,%d,%d,%d,%d%s%s>%s", d.dtype == DT_BF16 ? "bf16" : "f32", d.bm, d.bn, d.wm, d.wn,
                 d.nst, d.pipe, d.ldr, d.lnf ? ",ln" : "", d.cm ? ",cm" : "", d.splits > 1 ? "/splitk" : "");
   return buf;
@@ -1213,6 +1330,7 @@ int igemm_pick_bn(int n_real, int epi) {
 // returns the number of K slices (1 = no split).  Mirrors dispatch()'s tile choice.
 int igemm_plan_splits(const IgemmParams& p, int dtype) {
   if (p.epi != EPI_STORE || p.rowstats) return 1;
+  if (g_big == kDefaultPolicy && g_force_cfg < 0 && igemm_ws_ok(p, dtype)) return igemm_ws_splits(p);
   if (const TunedEntry* e = tuned_lookup(p, dtype)) return e->splits;
   const int bke = dtype == DT_BF16 ? 64 : 32;
   const int bn = p.N % 160 == 0 ? 160 : (p.N % 128 == 0 ? 128 : (p.N % 64 == 0 ? 64 : 32));

@@ -56,6 +56,7 @@ struct IgemmParams {
   int N = 0;        // packed rows of W (multiple of the N tile)
   int n_valid = 0;  // real output channels (store mask)
   const void* W = nullptr;       // [N][taps*(C0+C1)] compute dtype, K = (tap, channel)
+  const void* Wf = nullptr;      // the same matrix fragment-major (launch_pack_ws) or null: what igemm_ws_kernel streams
   const float* bias = nullptr;   // [N] (packed order) or null
   const float* rowbias = nullptr;  // [B][rb_stride] per-image bias (time embedding) or null
   int rb_stride = 0;
@@ -79,6 +80,10 @@ struct IgemmParams {
   const void* zeros = nullptr;   // >= 16 B of zeros (set by the launcher)
   // set by the launcher: divisions the kernels need (by Ho*Wo, Wo, the number of n tiles / tiles / K slices, K tiles per tap)
   FastDiv fd_hwo, fd_wo, fd_nt, fd_ntiles, fd_nsplit, fd_tpt;
+  int x3 = 0;                    // fp32 launches only: split-bf16 arithmetic (hi + lo, three bf16 MFMAs per product block) instead of
+                                 // the exact fp32 MFMA - compute_dtype "bf16x3" of the handles
+  int wt = 0;                    // row-major epilogue stores write through (sc1) instead of staying dirty in the XCD's L2 until the
+                                 // end-of-kernel write-back (set by the launcher from igemm_set_wt, debug key 18)
   int dbg = 0;                   // ablation flags for profiling experiments (results are wrong when != 0)
   unsigned long long* ts = nullptr;   // LDMSEG_IGEMM_ABLATE builds: per-workgroup s_memtime stamps (wave 0)
 };
@@ -99,16 +104,30 @@ void ops_bench_knob(int key, int value);   // ldmseg_bench_igemm (ops_api.hip): 
 void igemm_set_cm_mode(int mode);
 int igemm_get_cm_mode();
 bool igemm_conv_cm(int hw, int ctot, int n, int k, int stride, int up, int dtype);
+void igemm_set_wt(int on);       // experiment knob (debug key 18): write-through epilogue stores
+int igemm_get_wt();
 void igemm_force_cfg(int cfg);   // tuning tool: >= 0 runs every launch with that entry of the instantiation list, -1 = off
 int igemm_get_dbg();       // current (policy << 8) | ablation flags
 int igemm_default_dbg();   // the shipped value
 // template instantiation + plan of the most recent launch_igemm (test introspection)
-struct IgemmDispatch { int dtype, bm, bn, wm, wn, nst, pipe, ldr, splits, grid, lnf, cm; };
+struct IgemmDispatch { int dtype, bm, bn, wm, wn, nst, pipe, ldr, splits, grid, lnf, cm, ws; };   // ws: waves of igemm_ws_kernel (0: igemm_kernel)
 IgemmDispatch igemm_last_dispatch();
 std::string igemm_dispatch_name(const IgemmDispatch& d);
 void igemm_log_enable(int on);      // start (and clear) / stop recording the distinct instantiations launched
 void igemm_log_note(const char* name);   // recorded while logging is on (the fused feed-forward kernel: "mlp_fused<bf16,proj=P>")
 std::string igemm_log_read();       // newline-separated   // ablation flags (profiling only)   // K-loop ring depth (2, 3, 4) - tuning knob
+// igemm_ws.hip (round 5): weight-streaming kernel of the small maps - X through the LDS, every wave's weight rows straight
+// into its registers; writes split-K slabs only (launch_igemm runs the finish).  igemm_ws_ok: the launch shape / mode takes it.
+bool igemm_ws_ok(const IgemmParams& p, int dtype);
+int igemm_ws_splits(const IgemmParams& p);
+int launch_igemm_ws(const IgemmParams& p, hipStream_t s);
+// [N][K] bf16 (K a multiple of 64, N of 16) -> fragment-major: 1 KiB blocks [n / 16][K tile][k-group], lane l of a block =
+// the 16 bytes MFMA lane l wants: row 16 (n / 16) + (l & 15), K elements 64 kt + 32 kg + 8 (l >> 4) .. + 8
+int launch_pack_ws(const void* w_nk, void* out, int N, int K, hipStream_t s);
+bool igemm_ws_wants(int N, int K, int epi, int dtype);     // create time: hold the second packing for this layer?
+int igemm_ws_waves();
+void igemm_ws_set_mode(int mode, int max_m, int min_nk);   // bit 0: on, bit 1: 4-wave workgroups; 0 keeps a threshold
+int igemm_ws_get_mode();
 // tile the launcher would pick (for weight padding): N tile size for a given N.
 int igemm_pick_bn(int n_real, int epi);
 

@@ -343,6 +343,8 @@ static int op_igemm_impl(const float* x, const float* x2, const float* w, const 
                          int silu, int splits, int dtype, float* out, void* stream, int time_iters, float* us_per_launch) {
   hipStream_t s = (hipStream_t)stream;
   Temp t;
+  const int x3 = dtype == 2 ? 1 : 0;        // LDMSEG_BF16X3: fp32 storage, split-bf16 products
+  if (x3) dtype = DT_F32;
   const int a = bke(dtype);
   const int c0 = rupi(Ci, a), c1 = Ci2 ? rupi(Ci2, a) : 0;
   if (Ci2 && (Ci % a)) return -2;
@@ -395,6 +397,13 @@ static int op_igemm_impl(const float* x, const float* x2, const float* w, const 
   p.M = B * Ho * Wo; p.N = Np; p.n_valid = cout; p.W = wp; p.bias = bp;
   p.rowbias = rowbias; p.rb_stride = Co;
   p.resid = rp; p.ldr = cout; p.out = op; p.ldo = cout; p.epi = epi; p.silu = silu;
+  p.x3 = x3;
+  const size_t wbytes_ = (size_t)Np * k * k * ct * es(dtype);
+  if (dtype == DT_BF16 && !geglu && !cm && Np % 256 == 0 && (k * k * ct) % 64 == 0) {     // the fragment-major packing igemm_ws.hip streams
+    void* wf = t.get(wbytes_);
+    if (launch_pack_ws(wp, wf, Np, k * k * ct, s)) return -3;
+    p.Wf = wf;
+  }
   int sp = splits > 0 ? splits : igemm_plan_splits(p, dtype);
   if (sp > 1) { p.splits = sp; p.partial = (float*)t.get((size_t)sp * p.M * Np * sizeof(float)); }
   if (time_iters > 0 && g_bench_ln && !sp_gt1(sp) && !rowbias) {   // time the folded-LayerNorm instantiation (mean 0, rstd 1, c1 0)
@@ -412,19 +421,27 @@ static int op_igemm_impl(const float* x, const float* x2, const float* w, const 
     // the weights of a layer are cold in the real forward (1.6 GB of them stream through per step): rotate over copies
     const size_t wbytes = (size_t)Np * k * k * ct * es(dtype);
     int rot = g_bench_rot < 1 ? 1 : g_bench_rot;
-    std::vector<const void*> wc(1, wp);
+    std::vector<const void*> wc(1, wp), wfc(1, p.Wf);
     for (int i = 1; i < rot; ++i) {
       void* c = t.get(wbytes);
       if (!c) break;
       (void)hipMemcpyAsync(c, wp, wbytes, hipMemcpyDeviceToDevice, s);
+      const void* cf = nullptr;
+      if (p.Wf) {
+        void* q = t.get(wbytes);
+        if (!q) break;
+        (void)hipMemcpyAsync(q, p.Wf, wbytes, hipMemcpyDeviceToDevice, s);
+        cf = q;
+      }
       wc.push_back(c);
+      wfc.push_back(cf);
     }
     rot = (int)wc.size();
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    for (int i = 0; i < 3; ++i) { p.W = wc[i % rot]; (void)launch_igemm(p, dtype, s); }
+    for (int i = 0; i < 3; ++i) { p.W = wc[i % rot]; p.Wf = wfc[i % rot]; (void)launch_igemm(p, dtype, s); }
     (void)hipEventRecord(e0, s);
-    for (int i = 0; i < time_iters; ++i) { p.W = wc[(i + 3) % rot]; (void)launch_igemm(p, dtype, s); }
+    for (int i = 0; i < time_iters; ++i) { p.W = wc[(i + 3) % rot]; p.Wf = wfc[(i + 3) % rot]; (void)launch_igemm(p, dtype, s); }
     (void)hipEventRecord(e1, s);
     (void)hipEventSynchronize(e1);
     float ms = 0;
@@ -496,6 +513,8 @@ int ldmseg_op_ln_linear(const float* x, const float* gamma, const float* beta, c
                         int N, float eps, int geglu, int dtype, float* out, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   Temp t;
+  const int x3 = dtype == 2 ? 1 : 0;        // LDMSEG_BF16X3
+  if (x3) dtype = DT_F32;
   if (K % bke(dtype)) return -2;
   void* xp = t.get((size_t)M * K * es(dtype));
   to_dev_dtype(x, xp, (size_t)M * K, dtype, s);
@@ -528,6 +547,7 @@ int ldmseg_op_ln_linear(const float* x, const float* gamma, const float* beta, c
   p.src0 = xp; p.C0 = K; p.B = 1; p.Hi = p.Ho = M; p.Wi = p.Wo = 1;
   p.M = M; p.N = Np; p.n_valid = nout; p.W = wp; p.bias = c2; p.rowstats = stats; p.c1 = c1;
   p.out = op; p.ldo = nout; p.epi = epi;
+  p.x3 = x3;
   const int sp = igemm_plan_splits(p, dtype);
   if (sp > 1) { p.splits = sp; p.partial = (float*)t.get((size_t)sp * M * Np * sizeof(float)); }
   const int r = launch_igemm(p, dtype, s);

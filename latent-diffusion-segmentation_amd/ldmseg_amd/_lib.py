@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # LDMSEG_HIP_LIB: developer override used for same-box A/B runs of two builds; the shipped path is in-tree
 LIB_PATH = os.environ.get("LDMSEG_HIP_LIB") or os.path.join(_HERE, "libldmseg_hip.so")
 
-F32, BF16 = 0, 1
+F32, BF16, BF16X3 = 0, 1, 2
 PRED = {"epsilon": 0, "sample": 1, "v_prediction": 2}
 
 

@@ -33,7 +33,8 @@ class UNet(object):
         if self.device.type != "cuda":
             raise RuntimeError("UNet needs an MI355X device (no CPU fallback)")
         self.compute_dtype = {"bf16": _lib.BF16, torch.bfloat16: _lib.BF16, "bfloat16": _lib.BF16,
-                              "fp32": _lib.F32, "float32": _lib.F32, torch.float32: _lib.F32}[compute_dtype]
+                              "fp32": _lib.F32, "float32": _lib.F32, torch.float32: _lib.F32,
+                              "bf16x3": _lib.BF16X3}[compute_dtype]   # bf16x3: fp32 storage, GEMMs as three bf16 MFMAs (hi + lo)
         # what callers see as `unet.dtype` is the boundary dtype (the reference keeps the UNet fp32, main_ldm.py:168)
         self.dtype = torch.float32
         self.in_channels = int(in_channels)

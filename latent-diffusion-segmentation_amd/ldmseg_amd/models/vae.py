@@ -83,7 +83,7 @@ class GeneralVAESeg(object):
         if missing:
             raise KeyError(f"state dict lacks seg-VAE tensors, e.g. {missing[:3]}")
         cd = {"bf16": _lib.BF16, torch.bfloat16: _lib.BF16, "fp32": _lib.F32, torch.float32: _lib.F32,
-              "float32": _lib.F32, "bfloat16": _lib.BF16}[compute_dtype]
+              "float32": _lib.F32, "bfloat16": _lib.BF16, "bf16x3": _lib.BF16X3}[compute_dtype]
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
         cfg = _lib.VAECfg(in_channels, int_channels, out_channels, latent_channels, num_latents, num_upscalers,
                           upscale_channels, norm_num_groups, (C.c_int32 * 4)(*block_out_channels), cd, idx)
@@ -242,7 +242,7 @@ class GeneralVAEImage(object):
             # newer diffusers store the attention projections as 1x1 convs or Linear; both flatten to [512, 512]
             sd[k] = t.reshape(schema[k]) if tuple(t.shape) != tuple(schema[k]) else t
         cd = {"bf16": _lib.BF16, torch.bfloat16: _lib.BF16, "fp32": _lib.F32, torch.float32: _lib.F32,
-              "float32": _lib.F32, "bfloat16": _lib.BF16}[compute_dtype]
+              "float32": _lib.F32, "bfloat16": _lib.BF16, "bf16x3": _lib.BF16X3}[compute_dtype]
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
         cfg = _lib.VAEImageCfg(cd, idx)
         n, names, ptrs, numels, keep = _lib.weight_arrays(sd, self.device)

@@ -988,3 +988,134 @@ def test_step_tail_kernel(L, case):
         if selfc:
             exp[:, :, 8:12] = x0.cpu().reshape(B, 4, H * W).permute(0, 2, 1)
         assert torch.equal(xin.cpu(), bf16_round(exp)), case
+
+
+# ---- weight-streaming kernel of the small maps (igemm_ws.hip, round 5) ----
+# (B, Ci, Ci2, H, Co, k, stride, up, splits, residual, time-embedding row)
+WS_CASES = {
+    "m512_3x3": (8, 1280, 0, 8, 1280, 3, 1, 0, 0, 0, 1),          # the launch it was written for: M = 512, 180 K tiles, 12 slices of 15
+    "m512_res": (8, 1280, 0, 8, 1280, 3, 1, 0, 0, 1, 0),
+    "ragged_m": (3, 320, 0, 8, 256, 3, 1, 0, 0, 1, 1),            # M = 192: the second m tile is half empty, images end inside tiles
+    "ragged_map": (2, 320, 0, 7, 256, 3, 1, 0, 0, 0, 0),          # 7x7 maps: M = 98, rows of several images and padding taps everywhere
+    "stride2": (2, 320, 0, 16, 512, 3, 2, 0, 0, 0, 0),            # downsampler
+    "up": (2, 320, 0, 4, 256, 3, 1, 1, 0, 0, 0),                  # nearest x2 folded into the gather
+    "concat": (2, 320, 192, 8, 256, 3, 1, 0, 0, 0, 1),            # torch.cat partner: the source switches inside a tap
+    "lin_2560": (2, 2560, 0, 8, 256, 1, 1, 0, 0, 1, 0),           # 1x1: 40 K tiles
+    "slices7": (2, 640, 0, 8, 256, 3, 1, 0, 7, 0, 0),             # 90 K tiles over 7 slices: 12 / 13 tiles, none a multiple of four
+    "slices2": (1, 320, 0, 8, 512, 3, 1, 0, 2, 0, 0),             # 45 K tiles over 2 slices (22 / 23)
+    "slices45": (1, 320, 0, 8, 256, 3, 1, 0, 45, 0, 0),           # one K tile per slice: the whole ring is padding
+}
+
+
+@pytest.mark.parametrize("waves", [8, 4])
+@pytest.mark.parametrize("case", sorted(WS_CASES))
+def test_weight_streaming_kernel(L, case, waves):
+    """igemm_ws_kernel (X through the LDS, every wave's weight rows straight into its registers, split-K slabs + finish) against
+    F.conv2d on the bf16-rounded operands, on shapes that hit its edges: ragged M, every gather mode, slice lengths that are
+    not a multiple of the four-tile ring, both workgroup forms."""
+    B, Ci, Ci2, H, Co, k, stride, up, splits, use_res, use_rb = WS_CASES[case]
+    lib = L.lib()
+    saved = lib.ldmseg_debug_get(17)
+    g = torch.Generator().manual_seed(len(case) * 131 + waves)
+    ct = Ci + Ci2
+    x = torch.randn(B, Ci, H, H, generator=g)
+    x2 = torch.randn(B, Ci2, H, H, generator=g) if Ci2 else None
+    w = torch.randn(Co, ct, k, k, generator=g) / (ct * k * k) ** 0.5
+    b = torch.randn(Co, generator=g)
+    rb = torch.randn(B, Co, generator=g) if use_rb else None
+    xin = bf16_round(torch.cat([x, x2], 1) if Ci2 else x)
+    if up:
+        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(xin, bf16_round(w), b, stride=stride, padding=k // 2)
+    if rb is not None:
+        ref = ref + rb[:, :, None, None]
+    res = torch.randn(ref.shape, generator=g) if use_res else None
+    if res is not None:
+        ref = ref + bf16_round(res)
+    out = torch.empty(ref.shape, device="cuda")
+    dx, dx2, dw, db, dres, drb = dev(x), dev(x2), dev(w), dev(b), dev(res), dev(rb)
+    try:
+        # mode: on (| 4-wave workgroups), M <= 4096, >= 1 K tile per launch - the test shapes are smaller than the shipped thresholds
+        assert lib.ldmseg_debug_set(17, (1 | (2 if waves == 4 else 0)) | ((4096 // 4) << 8) | (1 << 20)) == 0
+        r = lib.ldmseg_op_igemm(P(dx), P(dx2), P(dw), P(db), P(dres), P(drb), B, Ci, Ci2, H, H, Co, k, stride, up, 0,
+                                0, splits, BF16, P(out), None)
+        assert r == 0, lib.ldmseg_last_error()
+        torch.cuda.synchronize()
+        name = L.igemm_last_kernel()
+    finally:
+        lib.ldmseg_debug_set(17, saved | ((1024 // 4) << 8) | (40 << 20))     # (the shipped thresholds; mode 0 = off is the default)
+    assert name.startswith("igemm_ws<") and f"w{waves}>" in name, name
+    assert rel_err(out, ref) < 8e-3, (case, name)
+    assert lib.ldmseg_debug_get(17) == saved
+
+
+# ---- split-bf16 GEMM arithmetic on fp32 operands (compute_dtype "bf16x3", round 5) ----
+X3_CASES = [
+    # B, Ci, Ci2, H, Co, k, stride, up, geglu, residual, time-embedding row
+    (8, 320, 0, 32, 320, 3, 1, 0, 0, 0, 1),      # 256-row tiles
+    (2, 640, 320, 16, 640, 3, 1, 0, 0, 1, 0),    # concat + residual, 64-row tiles
+    (8, 1280, 0, 8, 1280, 3, 1, 0, 0, 0, 1),     # K slices + finish
+    (2, 320, 0, 32, 2560, 1, 1, 0, 1, 0, 0),     # GEGLU
+    (2, 320, 0, 32, 320, 3, 2, 0, 0, 0, 0),      # stride 2
+    (1, 320, 0, 16, 4, 3, 1, 0, 0, 0, 0),        # narrow N (conv_out style)
+    (3, 96, 0, 5, 160, 3, 1, 0, 0, 0, 0),        # ragged everything
+]
+
+
+@pytest.mark.parametrize("case", X3_CASES)
+def test_split_bf16_gemm_vs_fp32_reference(L, case):
+    """dtype 2 of the operator ABI = LDMSEG_BF16X3: fp32 operands in HBM and LDS, hi/lo split in registers, three
+    v_mfma_f32_16x16x32_bf16 per product block.  Against F.conv2d in fp32 on the UNROUNDED operands: the bound of the exact fp32
+    kernels (1e-4 max-norm), i.e. an order of magnitude inside the north-star 1e-3."""
+    B, Ci, Ci2, H, Co, k, stride, up, geglu, use_res, use_rb = case
+    g = torch.Generator().manual_seed(sum(case))
+    ct = Ci + Ci2
+    x = torch.randn(B, Ci, H, H, generator=g)
+    x2 = torch.randn(B, Ci2, H, H, generator=g) if Ci2 else None
+    w = torch.randn(Co, ct, k, k, generator=g) / (ct * k * k) ** 0.5
+    b = torch.randn(Co, generator=g)
+    rb = torch.randn(B, Co, generator=g) if use_rb else None
+    xin = torch.cat([x, x2], 1) if Ci2 else x
+    if up:
+        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(xin, w, b, stride=stride, padding=k // 2)
+    if rb is not None:
+        ref = ref + rb[:, :, None, None]
+    if geglu:
+        a, gate = ref.chunk(2, 1)
+        ref = a * F.gelu(gate)
+    res = torch.randn(ref.shape, generator=g) if use_res else None
+    if res is not None:
+        ref = ref + res
+    out = torch.empty(ref.shape, device="cuda")
+    dx, dx2, dw, db, dres, drb = dev(x), dev(x2), dev(w), dev(b), dev(res), dev(rb)
+    r = L.lib().ldmseg_op_igemm(P(dx), P(dx2), P(dw), P(db), P(dres), P(drb), B, Ci, Ci2, H, H, Co, k, stride, up, geglu,
+                                0, 0, 2, P(out), None)
+    assert r == 0, L.lib().ldmseg_last_error()
+    torch.cuda.synchronize()
+    name = L.igemm_last_kernel()
+    assert name.startswith("igemm<f32,") and ",0,0" in name, name          # a plain-K-loop fp32 instantiation
+    e = rel_err(out, ref)
+    assert e < 1e-4, (case, name, e)
+
+
+@pytest.mark.parametrize("M,K,N,geglu", [(2048, 640, 1920, 0), (512, 1280, 10240, 1), (4096, 320, 960, 0)])
+def test_split_bf16_layernorm_folded_gemm(L, M, K, N, geglu):
+    """LayerNorm -> Linear / GEGLU with the split-bf16 products (the ',ln' plain-loop instantiations)."""
+    g = torch.Generator().manual_seed(M + N)
+    x = torch.randn(M, K, generator=g) * 1.5 + 3.0
+    gamma = 1 + 0.2 * torch.randn(K, generator=g)
+    beta = 0.2 * torch.randn(K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    y = F.linear(F.layer_norm(x, (K,), gamma, beta, 1e-5), w, b)
+    if geglu:
+        a, gate = y.chunk(2, -1)
+        y = a * F.gelu(gate)
+    out = torch.empty(y.shape, device="cuda")
+    dx, dg, db, dw, dbias = dev(x), dev(gamma), dev(beta), dev(w), dev(b)
+    assert L.lib().ldmseg_op_ln_linear(P(dx), P(dg), P(db), P(dw), P(dbias), M, K, N, 1e-5, geglu, 2, P(out), None) == 0
+    torch.cuda.synchronize()
+    name = L.igemm_last_kernel()
+    assert ",ln" in name and name.startswith("igemm<f32,"), name
+    assert rel_err(out, y) < 2e-4, name
