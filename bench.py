@@ -533,8 +533,9 @@ def main():
     if rank == 0 and world == 1 and not args.no_torch_reference and (B, L) == (8, 64):
         import subprocess
         try:
-            r_ = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "yardstick.py"), "--whole-only", "--batch", str(B),
-                                 "--latent", str(L)], capture_output=True, text=True, timeout=600)
+            r_ = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "yardstick.py"), "--whole-only", "--fast", "--batch", str(B),
+                                 "--latent", str(L)] + (["--compile"] if os.environ.get("LDMSEG_YARDSTICK_COMPILE") else []),
+                                capture_output=True, text=True, timeout=900)
             torch_ref = json.loads(r_.stdout.strip().splitlines()[-1]) if r_.returncode == 0 else {"error": r_.stderr[-300:]}
         except Exception as e:                     # the yardstick must never take the bench line down with it
             torch_ref = {"error": repr(e)[:300]}

@@ -1815,7 +1815,6 @@ int ldmseg_debug_set(int key, int value) {
   // 17: weight-streaming kernel of the small maps (igemm_ws.hip).  bits 0-2: mode (bit 0 on, bit 1 4-wave workgroups, bit 2 whole-k-group X buffers + 3-slot ring),
   // bits 8-19: largest M it takes (0: keep), bits 20-27: fewest K tiles (0: keep).  Default 1 | M <= 1024 | >= 40 K tiles
   if (key == 17) { igemm_ws_set_mode(value & 7, (value >> 8) & 0xfff ? ((value >> 8) & 0xfff) * 4 : 0, (value >> 20) & 0xff); ++g_plan_epoch; return 0; }
-  if (key == 18) { igemm_set_wt(value); return 0; }       // experiment: write-through (sc1) row-major epilogue stores of igemm_kernel
   if (key == 6 || key == 7) { ops_bench_knob(key, value); return 0; }   // ldmseg_bench_igemm: 6 = weight copies rotated, 7 = folded-LN launch
   static unsigned long long ts_ptr = 0;                // keys 3/4: low/high half of a device stamp buffer (ablate builds)
   if (key == 3) { ts_ptr = (ts_ptr & 0xffffffff00000000ull) | (unsigned)value; igemm_set_tsbuf((void*)(uintptr_t)ts_ptr); return 0; }
@@ -1832,7 +1831,6 @@ int ldmseg_debug_get(int key) {
   if (key == 16) return proj_qkv_get_mode();
   if (key == 15) return attention_mx_get_mode();
   if (key == 17) return igemm_ws_get_mode();
-  if (key == 18) return igemm_get_wt();
   if (key == 10) { const long long n = gn_coop_fallbacks(nullptr); return n > 0x7fffffffll ? 0x7fffffff : (int)n; }   // ring regions (ldmseg_op_* launches)
   return 0;
 }

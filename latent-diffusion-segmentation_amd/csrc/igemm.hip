@@ -69,12 +69,6 @@ __device__ __forceinline__ void glds16_sbase(unsigned voff, const void* sbase, u
       : "memory");
 }
 
-// 16-byte store that writes through to the device-coherent level (sc1) instead of leaving a dirty line in the XCD's L2
-__device__ __forceinline__ void store16_wt(void* dst, const uint4& v) {
-  const u32x4 d = {v.x, v.y, v.z, v.w};
-  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(dst), "v"(d) : "memory");
-}
-
 struct RowInfo {
   int pix_base;  // b * Hi * Wi
   int iy0, ix0;  // top-left input coordinate (logical, before upsample shift)
@@ -499,10 +493,8 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LDR) * 64, (WAVES_M * WAVES_N 
 #pragma unroll
               for (int e = 0; e < E; ++e) v[e] = silu_f(v[e]);
             }
-            if (!DBG(p, 64)) {
-              if (p.wt) store16_wt((T*)p.out + (size_t)m * p.ldo + n, Chunk<T>::pack(v));
-              else *(uint4*)((T*)p.out + (size_t)m * p.ldo + n) = Chunk<T>::pack(v);
-            } else asm volatile("" ::"v"(v[0]), "v"(v[E - 1]));
+            if (!DBG(p, 64)) *(uint4*)((T*)p.out + (size_t)m * p.ldo + n) = Chunk<T>::pack(v);
+            else asm volatile("" ::"v"(v[0]), "v"(v[E - 1]));
           }
         }
       }
@@ -598,10 +590,8 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LDR) * 64, (WAVES_M * WAVES_N 
                 const f32x4 t = *(const f32x4*)(sp + q * 16);
                 v[q * 4 + 0] = t[0]; v[q * 4 + 1] = t[1]; v[q * 4 + 2] = t[2]; v[q * 4 + 3] = t[3];
               }
-              if (!DBG(p, 64)) {
-                if (p.wt) store16_wt((T*)p.out + (size_t)m * p.ldo + oc0 + cc * E, Chunk<T>::pack(v));
-                else *(uint4*)((T*)p.out + (size_t)m * p.ldo + oc0 + cc * E) = Chunk<T>::pack(v);
-              } else asm volatile("" ::"v"(v[0]), "v"(v[E - 1]));
+              if (!DBG(p, 64)) *(uint4*)((T*)p.out + (size_t)m * p.ldo + oc0 + cc * E) = Chunk<T>::pack(v);
+              else asm volatile("" ::"v"(v[0]), "v"(v[E - 1]));
             }
           }
         }
@@ -1039,7 +1029,6 @@ int g_big = kDefaultPolicy;      // bit0: 8-wave 256-row tiles with a 3-stage ri
                      // bit2: lone 64-row 4-stage tiles; bit3: pipelined K loop on the 256-row tiles; bit4: 8-wave 128-row
                      // tiles (+ loader waves on long K); bit5: loader waves on the 256-row tiles (long K / GEGLU)
 
-int g_wt = 0;                    // igemm_set_wt
 int g_force_cfg = -1;            // tools/tune_igemm.py: run every launch with this entry of the instantiation list
 int g_cm_mode = -1;              // igemm_set_cm_mode
 
@@ -1065,7 +1054,6 @@ template <typename T, int BM, int BN, int WM, int WN, int NST = 2, bool PIPE = f
 int run(const IgemmParams& pin, hipStream_t s) {
   IgemmParams p = pin;
   p.dbg = g_dbg;
-  p.wt = g_wt;
   p.ts = (unsigned long long*)g_tsbuf;
   p.zeros = zero_page();
   if (!p.zeros) return -3;
@@ -1293,8 +1281,6 @@ int igemm_warm() { return zero_page() ? 0 : -3; }
 const void* igemm_zero_page() { return zero_page(); }
 void igemm_set_tsbuf(void* b) { g_tsbuf = b; }
 void igemm_force_cfg(int cfg) { g_force_cfg = cfg; }
-void igemm_set_wt(int on) { g_wt = on ? 1 : 0; }
-int igemm_get_wt() { return g_wt; }
 void igemm_set_dbg(int f) { g_dbg = f & 0xff; g_big = (f >> 8) & 63; }   // bits 8-13 select the tile policy
 int igemm_get_dbg() { return (g_big << 8) | g_dbg; }
 int igemm_default_dbg() { return kDefaultPolicy << 8; }

@@ -82,8 +82,6 @@ struct IgemmParams {
   FastDiv fd_hwo, fd_wo, fd_nt, fd_ntiles, fd_nsplit, fd_tpt;
   int x3 = 0;                    // fp32 launches only: split-bf16 arithmetic (hi + lo, three bf16 MFMAs per product block) instead of
                                  // the exact fp32 MFMA - compute_dtype "bf16x3" of the handles
-  int wt = 0;                    // row-major epilogue stores write through (sc1) instead of staying dirty in the XCD's L2 until the
-                                 // end-of-kernel write-back (set by the launcher from igemm_set_wt, debug key 18)
   int dbg = 0;                   // ablation flags for profiling experiments (results are wrong when != 0)
   unsigned long long* ts = nullptr;   // LDMSEG_IGEMM_ABLATE builds: per-workgroup s_memtime stamps (wave 0)
 };
@@ -104,8 +102,6 @@ void ops_bench_knob(int key, int value);   // ldmseg_bench_igemm (ops_api.hip): 
 void igemm_set_cm_mode(int mode);
 int igemm_get_cm_mode();
 bool igemm_conv_cm(int hw, int ctot, int n, int k, int stride, int up, int dtype);
-void igemm_set_wt(int on);       // experiment knob (debug key 18): write-through epilogue stores
-int igemm_get_wt();
 void igemm_force_cfg(int cfg);   // tuning tool: >= 0 runs every launch with that entry of the instantiation list, -1 = off
 int igemm_get_dbg();       // current (policy << 8) | ablation flags
 int igemm_default_dbg();   // the shipped value

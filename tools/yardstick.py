@@ -137,6 +137,7 @@ def main():
     ap.add_argument("--latent", type=int, default=64)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "yardstick.txt"))
     ap.add_argument("--compile", action="store_true", help="add a torch.compile(mode='max-autotune') leg to the whole forward (minutes)")
+    ap.add_argument("--fast", action="store_true", help="fp32: the eager leg only (bench.py's subprocess call; the tuned legs run in bf16)")
     ap.add_argument("--whole-only", action="store_true", help="only part (ii), print one JSON object (bench.py's torch_rocm_reference)")
     args = ap.parse_args()
     B, L = args.batch, args.latent
@@ -144,7 +145,7 @@ def main():
     from ldmseg_amd.models import UNet
     from oracle import unet as o_unet
     usd = weights.generate(weights.unet_schema(12, False), seed=0)
-    res = whole_forward(usd, B, L, UNet, o_unet, compile_leg=args.compile)
+    res = whole_forward(usd, B, L, UNet, o_unet, compile_leg=args.compile, fast=args.fast)
     if args.whole_only:
         print(json.dumps(res))
         return
@@ -228,7 +229,7 @@ def main():
         fh.write("\n".join(lines) + "\n")
 
 
-def whole_forward(usd, B, L, UNet, o_unet, compile_leg=False):
+def whole_forward(usd, B, L, UNet, o_unet, compile_leg=False, fast=False):
     """ms per UNet forward: this library (bf16, fp32) and the oracle graph run by torch-ROCm eager on the same GPU."""
     dev = "cuda:0"
     x = torch.randn(B, 12, L, L, generator=torch.Generator().manual_seed(0))
@@ -277,6 +278,8 @@ def whole_forward(usd, B, L, UNet, o_unet, compile_leg=False):
                 o_unet.attention = math_attention
                 res[f"torch_rocm_eager_{mode}_math_attention_ms"] = t_ms(lambda: o_unet.unet_forward(sd, xt, tt))
                 o_unet.attention = sdpa_attention
+                if fast and mode == "fp32":        # bench.py's call: the tuned legs only for the headline dtype
+                    raise StopIteration
                 # round 5: the comparator at its best, not at its defaults.
                 # (a) MIOpen find mode: every conv shape benchmarked once, the fastest solver kept
                 torch.backends.cudnn.benchmark = True
@@ -304,6 +307,8 @@ def whole_forward(usd, B, L, UNet, o_unet, compile_leg=False):
                     except Exception as e:            # Inductor failures must not take the yardstick down
                         res["torch_compile_error"] = repr(e)[:300]
                 del sd_cl
+            except StopIteration:
+                pass
             except RuntimeError as e:          # e.g. an op without a bf16 kernel: say so instead of dying
                 res.setdefault(f"torch_rocm_eager_{mode}_ms", None)
                 res[f"torch_rocm_eager_{mode}_error"] = str(e)[:200]
