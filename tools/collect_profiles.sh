@@ -2,7 +2,7 @@
 # Run on the GPU box from the repo root (gpurun): every measurement profiles/ holds for one round, from ONE box.
 #   bash tools/collect_profiles.sh r02     -> gpurun_out/prof_r02/...;  then locally: python tools/import_profiles.py r02
 set -x
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_$TAG; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 BENCH="python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-images --no-extras --no-torch-reference --profile-steps 0"
@@ -22,14 +22,20 @@ python bench.py > $O/bench_default.json 2> $O/bench_default.err
 python bench.py --batch 4 --latent 128 --steps 20 --warmup 2 --no-cpu-baseline --no-extras --no-images > $O/bench_config4_b4_l128_bf16.json 2>/dev/null
 python bench.py --batch 4 --latent 128 --steps 20 --warmup 2 --attention-fp8 16384 --no-cpu-baseline --no-extras --no-images > $O/bench_config4_b4_l128_fp8attn.json 2>/dev/null
 # round 4: same-box comparisons
-python tools/yardstick.py --out $O/yardstick.txt > $O/yardstick.log 2>&1
+timeout 1500 python tools/yardstick.py --compile --out $O/yardstick.txt > $O/yardstick.log 2>&1
 python tools/ff_bench.py 32768 65536 > $O/ff_bench.txt 2>&1
 python tools/tin_bench.py 32768 65536 2>&1 | grep -v amdgpu.ids > $O/tin_bench.txt
 python tools/attn8_bench.py > $O/attn8_bench.txt 2>&1; python tools/attn8_bench.py 4 4096 320 >> $O/attn8_bench.txt 2>&1
 python tools/attn8_acc.py 2>&1 | grep "N=" > $O/attn8_acc.txt
 python tools/attn4_bench.py 2>&1 | grep -v amdgpu.ids > $O/attn4_bench.txt
 python tools/ab_forward.py "12=0,14=0,16=0,2=7" "12=3,14=0,16=0,2=7" "12=3,14=1,16=0,2=7" "12=3,14=1,16=3,2=7" "12=3,14=1,16=3,2=0" --rounds 3 > $O/ab_knobs.txt 2>&1
-[ -f scratch/lib_r03.so ] && { LDMSEG_HIP_LIB=scratch/lib_r03.so python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras --no-images --no-torch-reference --profile-steps 0 > $O/bench_r03_lib_same_box.json 2>/dev/null; }
+# round 5: same-box A/B against the round-4 kernels (scratch/lib_r04.so = the library at the first round-5 commit: round-4 kernels + ABI additions)
+[ -f scratch/lib_r04.so ] && { LDMSEG_HIP_LIB=scratch/lib_r04.so python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras --no-images --no-torch-reference --profile-steps 0 > $O/bench_r04_lib_same_box.json 2>/dev/null; python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras --no-images --no-torch-reference --profile-steps 0 > $O/bench_this_lib_same_box.json 2>/dev/null; }
+# round 5: the weight-streaming kernel (opt-in) against igemm_kernel on the small-map shapes, cold weights; the parity-grade modes
+( for i in 43 44 46 50 30 33 34 38; do for ws in 0 0x20001 0x20005 0x20003; do ROT=1 WS=$ws python tools/kbench.py igemm1 $i 2>&1 | grep "M=" | sed "s/^/ws=$ws /"; done; done ) > $O/kbench_ws.txt 2>&1
+python tools/fam.py bf16x3 fp32 bf16 2>&1 | grep -v amdgpu.ids > $O/modes_ms_per_forward.txt
+[ -f scratch/lib_stamp.so ] && { export LDMSEG_OP_TIMING_NHWC=1; for shape in "320 64 320" "640 32 640" "1280 16 1280" "320 64 320 1" "640 32 640 1"; do LDMSEG_HIP_LIB=scratch/lib_stamp.so python tools/stamps2.py $shape 2>&1 | grep -v amdgpu.ids; done > $O/igemm_stamps.txt; unset LDMSEG_OP_TIMING_NHWC; }
+[ -f scratch/lib_r03.so ] && false && { LDMSEG_HIP_LIB=scratch/lib_r03.so python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras --no-images --no-torch-reference --profile-steps 0 > $O/bench_r03_lib_same_box.json 2>/dev/null; }
 python tools/kbench.py gn > $O/kbench_groupnorm.txt 2>&1
 python tools/kbench.py attn > $O/kbench_attention.txt 2>&1
 for u in mfma_lds mfma_lds2 buf_lds valu_trans copy_floor launch_floor barrier_cost mx_probe; do [ -x tools/ubench/bin/$u ] && timeout 300 tools/ubench/bin/$u > $O/ubench_$u.txt 2>&1; done
