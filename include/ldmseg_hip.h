@@ -293,9 +293,14 @@ int ldmseg_profile_dump(const char* path);
  * convert instead of the direct e4m3 byte - attention_mx.hip); key 16 = row-local fusion of the 320-channel transformer entry
  * (proj_in -> LayerNorm_1 -> q|k|v in one launch, tproj.hip; bit 0 on, bit 1 loader block rotation; default 3, 0 = the unfused
  * launches); key 2 values: 0 = shipped rule, 7 = the round-3 rule (attention3.hip at head dim 40), 11..14 = attention4.hip forced
- * (8 / 4 waves, lazily tracked / every-tile maxima). */
+ * (8 / 4 waves, lazily tracked / every-tile maxima); key 17 (round 5) = weight-streaming kernel of the small maps (igemm_ws.hip:
+ * X through the LDS, every wave's weight rows straight into its registers): bits 0-2 mode (bit 0 on, bit 1 4-wave workgroups, bit 2
+ * whole-k-group X buffers with a 3-slot ring), bits 8-19 largest M / 4, bits 20-27 fewest K tiles; default 0 = off (measured level
+ * with igemm_kernel); must be set BEFORE a handle is created (the handle then holds the fragment-major weight packing);
+ * key 19 = resnet conv2 + conv_shortcut as one launch with an extra centre tap (bf16; default 1, 0 = two launches);
+ * key 20 = ff.net.2 and proj_out of the 640- / 1280-channel transformers as one chained Linear over [g | h] (bf16; default 1). */
 int ldmseg_debug_set(int key, int value);
-/* current value of a knob (keys 1, 9, 12, 14, 15, 16); key -1 = the shipped default of key 1.  Tests restore through this, never a literal.
+/* current value of a knob (keys 1, 9, 12, 14, 15, 16, 17, 19, 20); key -1 = the shipped default of key 1.  Tests restore through this, never a literal.
  * key 10 = number of cooperative-GroupNorm workgroups that took the self-computing path in ldmseg_op_* launches so far. */
 int ldmseg_debug_get(int key);
 

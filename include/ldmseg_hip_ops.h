@@ -64,6 +64,13 @@ int ldmseg_op_transformer_in(const float* x, const float* wp, const float* bp, c
 int ldmseg_op_igemm(const float* x, const float* x2, const float* w, const float* bias, const float* resid,
                     const float* rowbias, int B, int Ci, int Ci2, int H, int W, int Co, int k, int stride, int up, int geglu,
                     int silu, int splits, int dtype, float* out, void* stream);
+/* F.conv2d(h, w2, b2, padding=1) + F.conv2d(torch.cat([xs, xs2], 1), ws, bs): the tail of diffusers' ResnetBlock2D where
+ * cin != cout (conv2 + conv_shortcut, ldmseg/models/unet.py:361-425 run them through diffusers 0.16.1's resnet.py) as the
+ * engine's ONE bf16 launch with an extra centre tap.  xs2 NULL / Cs2 = 0 when the shortcut input is not a concat.  iters > 0
+ * additionally times `iters` launches (us_per_launch).  -4: the shape has no such launch (the engine then runs two convs). */
+int ldmseg_op_conv3x3_plus_1x1(const float* h, const float* w2, const float* b2, const float* xs, const float* xs2, const float* ws,
+                               const float* bs, int B, int C, int Cs, int Cs2, int H, int W, int Co, int splits, int dtype, float* out,
+                               int iters, float* us_per_launch, void* stream);
 /* [silu](F.group_norm(F.conv2d(x, w, bias, padding=1) + rowbias[b,:,None,None], 32, gamma, beta, eps)) the way the engine runs
  * resnet conv1 -> norm2 on small maps: the conv as `splits` (>= 2) K slices, then ONE kernel that sums the slices, adds bias and
  * time-embedding row and normalises (launch_finish_groupnorm).  Returns -4 when the shape has no fused instantiation. */

@@ -25,6 +25,7 @@ thread_local std::string g_err;
 // tile policy and forced instantiation decide the split-K slice counts, i.e. the size of the partial-sum scratch).
 // Handles remember the epoch their cached plan was made under and re-plan when it moved.
 int g_plan_epoch = 0;
+int g_ffp_mode = 1;     // debug key 20: 1 (default) = ff.net.2 and proj_out of the 640- / 1280-channel transformers as one chained Linear
 int fail(int code, const std::string& msg) {
   g_err = msg;
   return code;
@@ -309,11 +310,12 @@ struct Exec {
     }
     // GEGLU: n_valid counts the OUTPUT channels, the GEMM computes value and gate columns for each
     const double ncols = (p.epi == EPI_GEGLU) ? 2.0 * p.n_valid : (double)p.n_valid;
-    const double flops = 2.0 * p.M * ncols * p.taps * (p.C0 + p.C1);
-    const double bytes = ((double)p.M * (p.C0 + p.C1) + (double)p.N * p.taps * (p.C0 + p.C1) + (double)p.M * p.n_valid) * esize(dt);
+    const int ktot = p.taps * (p.C0 + p.C1) + p.C2 + p.C3;
+    const double flops = 2.0 * p.M * ncols * ktot;
+    const double bytes = ((double)p.M * (p.C0 + p.C1 + p.C2 + p.C3) + (double)p.N * ktot + (double)p.M * p.n_valid) * esize(dt);
     std::string label;
     if (g_prof.on && !dry())
-      label = "M=" + std::to_string(p.M) + " N=" + std::to_string((int)ncols) + " K=" + std::to_string(p.taps * (p.C0 + p.C1)) +
+      label = "M=" + std::to_string(p.M) + " N=" + std::to_string((int)ncols) + " K=" + std::to_string(ktot) + (p.C2 ? "(+1x1 " + std::to_string(p.C2 + p.C3) + ")" : "") +
               " taps=" + std::to_string(p.taps) + " stride=" + std::to_string(p.stride) + " up=" + std::to_string(p.up) +
               " epi=" + std::to_string(p.epi) + " splits=" + std::to_string(p.splits);
     ProfScope ps(0, s, flops, bytes, dry(), label);
@@ -345,6 +347,31 @@ struct Exec {
     if (resid) { p.resid = resid->p; p.ldr = resid->C; }
     p.out = out->p; p.ldo = w.n_valid;
     p.epi = EPI_STORE; p.silu = silu;
+    return igemm(p);
+  }
+
+  // resnet tail: out = conv2(h) + conv_shortcut(cat([x, x2])) as one launch (ResnetW::conv2x); false = the launch has no
+  // extra-tap form here (fp32, debug key 19 off, a forced tile policy ...): the caller runs the two convs
+  bool conv_xt_ok(const ConvW& w, const Act& h, const Act& x, const Act* x2) const {
+    if (!w.w) return false;
+    IgemmParams p;
+    p.C0 = h.C; p.taps = 9; p.N = w.N; p.src2 = x.p ? x.p : (const void*)1; p.C2 = x.C;
+    if (x2) { p.src3 = x2->p ? x2->p : (const void*)1; p.C3 = x2->C; }
+    return igemm_xt_ok(p, dt);
+  }
+  int conv_xt(const ConvW& w, const Act& h, const Act& x, const Act* x2, Act* out) {
+    if (h.C != w.cin_pad) return fail(LDMSEG_E_SHAPE, "conv_xt: channel mismatch");
+    *out = new_act(w.n_valid, h.H, h.W, true);
+    IgemmParams p;
+    p.src0 = h.p; p.C0 = h.C;
+    p.src2 = x.p; p.C2 = x.C;
+    if (x2) { p.src3 = x2->p; p.C3 = x2->C; }
+    p.B = B; p.Hi = p.Ho = h.H; p.Wi = p.Wo = h.W;
+    p.taps = 9; p.stride = 1; p.up = 0; p.pad = -1;
+    p.M = B * h.H * h.W; p.N = w.N; p.n_valid = w.n_valid;
+    p.W = w.w; p.bias = w.bias;
+    p.out = out->p; p.ldo = w.n_valid;
+    p.epi = EPI_STORE;
     return igemm(p);
   }
 
@@ -432,6 +459,7 @@ constexpr int kTimeDim = 1280;
 struct ResnetW {
   NormW norm1, norm2;
   ConvW conv1, conv2, shortcut;
+  ConvW conv2x;           // bf16, has_shortcut: conv2 and conv_shortcut as ONE matrix [N][9 cout | cin], bias = b2 + bs (IgemmParams::src2)
   bool has_shortcut = false;
   int cin = 0, cout = 0, temb_off = 0;
 };
@@ -439,6 +467,7 @@ struct TransformerW {
   int C = 0;
   NormW norm, ln1, ln3;
   ConvW proj_in, qkv, attn_out, ff1, ff2, proj_out;
+  ConvW ffp;                    // bf16, levels without the row-local fused kernel: ff.net.2 and proj_out as ONE Linear over [g | h] (round 5)
   void* mlp_stream = nullptr;   // 320-channel level, bf16: the feed-forward's weights as one consumption-ordered stream (tfuse.hip)
   void* in_stream = nullptr;    // the same for proj_in | to_q | to_k | to_v (tproj.hip)
   float* in_bias = nullptr;     // [4][C]: proj_in bias | W_q beta | W_k beta | W_v beta
@@ -512,6 +541,19 @@ int build_resnet(Builder& b, const std::string& p, int cin, int cout, int* temb_
   TRY(b.conv(p + "conv2", cout, cout, 3, cout, &r->conv2, true, 0, EPI_STORE, cout <= 640));
   r->has_shortcut = cin != cout;
   if (r->has_shortcut) TRY(b.conv(p + "conv_shortcut", cout, cin, 1, cin, &r->shortcut));
+  // conv2(h) + conv_shortcut(x) is one accumulation over K = 9 cout + cin: a second packing with the shortcut's columns behind
+  // conv2's, run as one launch with an extra centre tap (igemm.hip, XT) - the shortcut's own launch, its output tensor and the
+  // residual read of conv2's epilogue disappear (14 resnets of the UNet)
+  if (r->has_shortcut && b.dt == DT_BF16 && r->conv2.N == r->shortcut.N && r->conv2.N % 160 == 0 && cin % bke(b.dt) == 0 && cout % bke(b.dt) == 0) {
+    ConvW& x = r->conv2x;
+    x.N = r->conv2.N; x.n_valid = r->conv2.n_valid; x.cin_pad = cout; x.taps = 9; x.cout = cout;
+    TRY(b.arena->alloc(&x.w, (size_t)x.N * (9 * cout + cin) * esize(b.dt)));
+    TRY(launch_concat_rows(r->conv2.w, 9 * cout, r->shortcut.w, cin, x.w, x.N, b.dt, b.s));
+    void* pb;
+    TRY(b.arena->alloc(&pb, x.N * sizeof(float)));
+    x.bias = (float*)pb;
+    TRY(launch_vec_add(r->conv2.bias, r->shortcut.bias, x.bias, x.N, b.s));
+  }
   r->temb_off = *temb_off;
   *temb_off += cout;
   return 0;
@@ -592,6 +634,31 @@ int build_transformer(Builder& b, const std::string& p, int C, TransformerW* t) 
   if (const size_t sb = (dt == DT_BF16 && t->ff1.N == 8 * C && t->ff2.N == C && t->proj_out.N == C) ? mlp_fused_stream_bytes(C) : 0) {
     TRY(b.arena->alloc(&t->mlp_stream, sb));
     TRY(launch_pack_mlp_stream(t->ff1.w, t->ff2.w, t->proj_out.w, t->mlp_stream, C, b.s));
+  }
+  // proj_out(h + ff.net.2(g)) + x has no nonlinearity between the two Linears (the transformer block ends with the feed-forward's
+  // residual, Transformer2DModel.proj_out follows): = [Wp W2 | Wp] [g | h] + (bp + Wp b2) + x.  Same FLOPs (2 M C 5C), one launch
+  // and one [M, C] round trip fewer: the levels that do not run the row-local fused kernel hold the chained matrix.
+  if (dt == DT_BF16 && !t->mlp_stream && C % 160 == 0 && t->ff2.N == C && t->proj_out.N == C) {
+    const float *w2, *b2, *wp, *bp;
+    TRY(b.wm->get(tb + "ff.net.2.weight", (int64_t)C * 4 * C, &w2));
+    TRY(b.wm->get(tb + "ff.net.2.bias", C, &b2));
+    TRY(b.wm->get(p + "proj_out.weight", (int64_t)C * C, &wp));
+    TRY(b.wm->get(p + "proj_out.bias", C, &bp));
+    void* wcat;
+    HIP_TRY(hipMalloc(&wcat, (size_t)C * 5 * C * sizeof(float)));
+    b.temps.push_back(wcat);
+    void* bcat;
+    TRY(b.arena->alloc(&bcat, C * sizeof(float)));
+    TRY(launch_chain_weights(wp, w2, b2, bp, (float*)wcat, (float*)bcat, C, b.s));
+    std::vector<int> ident(C);
+    for (int r = 0; r < C; ++r) ident[r] = r;
+    int* dident;
+    TRY(b.upload_ints(ident, &dident));
+    ConvW& f = t->ffp;
+    f.N = C; f.n_valid = C; f.cin_pad = 5 * C; f.taps = 1; f.cout = C;
+    TRY(b.arena->alloc(&f.w, (size_t)C * 5 * C * esize(dt)));
+    TRY(launch_repack_rows((const float*)wcat, f.w, dident, C, 5 * C, dt, b.s));
+    f.bias = (float*)bcat;
   }
   if (const size_t sb = (dt == DT_BF16 && t->proj_in.N == C && t->proj_in.cin_pad == C && t->qkv.N == 3 * C) ? proj_qkv_stream_bytes(C) : 0) {
     TRY(b.arena->alloc(&t->in_stream, sb));
@@ -691,6 +758,11 @@ int run_resnet(Exec& ex, const ResnetW& r, const Act& x, const Act* skip, const 
   TRY(ex.groupnorm(r.norm1, x, skip, 1e-5f, 1, &n1));
   TRY(ex.conv_groupnorm(r.conv1, n1, temb + r.temb_off, temb_stride, r.norm2, 1e-5f, 1, &n2));
   const Act* resid = &x;
+  if (r.has_shortcut && ex.conv_xt_ok(r.conv2x, n2, x, skip)) {
+    TRY(ex.conv_xt(r.conv2x, n2, x, skip, out));
+    ws->reset(m);
+    return 0;
+  }
   if (r.has_shortcut) {
     TRY(ex.conv(r.shortcut, x, skip, &sc, 1, 0, false, nullptr, 0, nullptr));
     resid = &sc;
@@ -790,6 +862,12 @@ int run_transformer(Exec& ex, const TransformerW& t, const Act& x, Act* out) {
     p.rowstats = stats; p.c1 = t.ff1.c1;
     p.out = ff.p; p.ldo = 4 * C; p.epi = EPI_GEGLU;
     TRY(ex.igemm(p));
+  }
+  if (t.ffp.w && g_ffp_mode) {
+    // out = proj_out(h + ff.net.2(g)) + x as one Linear over torch.cat([g, h], -1) (TransformerW::ffp)
+    TRY(ex.conv(t.ffp, ff, &h, out, 1, 0, true, nullptr, 0, &x));
+    ws->reset(m);
+    return 0;
   }
   {
     IgemmParams p;
@@ -1815,6 +1893,8 @@ int ldmseg_debug_set(int key, int value) {
   // 17: weight-streaming kernel of the small maps (igemm_ws.hip).  bits 0-2: mode (bit 0 on, bit 1 4-wave workgroups, bit 2 whole-k-group X buffers + 3-slot ring),
   // bits 8-19: largest M it takes (0: keep), bits 20-27: fewest K tiles (0: keep).  Default 1 | M <= 1024 | >= 40 K tiles
   if (key == 17) { igemm_ws_set_mode(value & 7, (value >> 8) & 0xfff ? ((value >> 8) & 0xfff) * 4 : 0, (value >> 20) & 0xff); ++g_plan_epoch; return 0; }
+  if (key == 19) { igemm_set_xt_mode(value); ++g_plan_epoch; return 0; }   // 1 (default): resnet conv2 + conv_shortcut as one launch (bf16)
+  if (key == 20) { g_ffp_mode = value ? 1 : 0; ++g_plan_epoch; return 0; }
   if (key == 6 || key == 7) { ops_bench_knob(key, value); return 0; }   // ldmseg_bench_igemm: 6 = weight copies rotated, 7 = folded-LN launch
   static unsigned long long ts_ptr = 0;                // keys 3/4: low/high half of a device stamp buffer (ablate builds)
   if (key == 3) { ts_ptr = (ts_ptr & 0xffffffff00000000ull) | (unsigned)value; igemm_set_tsbuf((void*)(uintptr_t)ts_ptr); return 0; }
@@ -1831,6 +1911,8 @@ int ldmseg_debug_get(int key) {
   if (key == 16) return proj_qkv_get_mode();
   if (key == 15) return attention_mx_get_mode();
   if (key == 17) return igemm_ws_get_mode();
+  if (key == 19) return igemm_get_xt_mode();
+  if (key == 20) return g_ffp_mode;
   if (key == 10) { const long long n = gn_coop_fallbacks(nullptr); return n > 0x7fffffffll ? 0x7fffffff : (int)n; }   // ring regions (ldmseg_op_* launches)
   return 0;
 }

@@ -123,7 +123,8 @@ constexpr bool epi_stage_dedicated() { return epi_stage_bytes<BM, BN, WAVES_M, W
 // measured +10 us per launch with the LayerNorm branch merely present.
 // CM: channel-major K order of a 3x3 conv (IgemmParams::cm).  A separate instantiation as well: carried as a run-time
 // branch it cost every launch of the family 2-5 % (measured; scalar registers and code in the K loop's DMA step).
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int NST, bool PIPE, int LDR, bool LNF, bool CM = false>
+// XT: the launch carries an extra centre tap (IgemmParams::src2 / C2 / src3 / C3).  A separate instantiation for the same reason.
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int NST, bool PIPE, int LDR, bool LNF, bool CM = false, bool XT = false>
 __global__ __launch_bounds__((WAVES_M * WAVES_N + LDR) * 64, (WAVES_M * WAVES_N + LDR) > 8 ? 3 : 2) void igemm_kernel(const IgemmParams p) {   // <=256 regs at 2 waves/SIMD; 12-wave workgroups (8 compute + 4 loader waves) need 3 per SIMD: <=168
   constexpr int NW = WAVES_M * WAVES_N;   // 4 waves (128-row tiles, 2 workgroups/CU) or 8 (256-row tiles)
   static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
@@ -165,8 +166,9 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LDR) * 64, (WAVES_M * WAVES_N 
   if (first_item >= nwork) return;
 
   const int Ctot = p.C0 + p.C1;
-  const int K = p.taps * Ctot;
+  const int K = p.taps * Ctot + (XT ? p.C2 + p.C3 : 0);
   const int nk_total = K / BKE;
+  const int nk_main = p.taps * (Ctot / BKE);       // K tiles of the 3x3 taps; XT: the extra tap's tiles follow
   const int Hlog = p.up ? 2 * p.Hi : p.Hi;
   const int Wlog = p.up ? 2 * p.Wi : p.Wi;
   const int pad = (p.taps == 9) ? (p.pad >= 0 ? p.pad : 1) : 0;
@@ -247,8 +249,13 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LDR) * 64, (WAVES_M * WAVES_N 
       }
     } else {
       const int tiles_per_tap = Ctot / BKE;
-      f_tap = fd_div(f_kt, p.fd_tpt);
-      f_cc = (f_kt - f_tap * tiles_per_tap) * BKE;
+      if (XT && f_kt >= nk_main) {          // the slice starts inside the extra tap
+        f_tap = 9;
+        f_cc = (f_kt - nk_main) * BKE;
+      } else {
+        f_tap = fd_div(f_kt, p.fd_tpt);
+        f_cc = (f_kt - f_tap * tiles_per_tap) * BKE;
+      }
     }
     need_setup = true;
   };
@@ -273,11 +280,15 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LDR) * 64, (WAVES_M * WAVES_N 
   // row only advances by 128 B per tile.  Row pointers are set up once per segment; rows whose tap
   // falls outside the image sit on the zero page with stride 0.
   auto seg_setup = [&]() __attribute__((always_inline)) {
-    const int ky = (p.taps == 9) ? f_tap / 3 : 0;
-    const int kx = (p.taps == 9) ? f_tap - ky * 3 : 0;
+    const bool xtap = XT && f_tap == 9;           // the extra tap reads the output pixel itself (window offset = pad)
+    const int ky = xtap ? pad : ((p.taps == 9) ? f_tap / 3 : 0);
+    const int kx = xtap ? pad : ((p.taps == 9) ? f_tap - ky * 3 : 0);
     const unsigned char* sbase;
     int cs, coff;
-    if (f_cc < p.C0) { sbase = (const unsigned char*)p.src0; cs = p.C0; coff = f_cc; }
+    if (xtap) {
+      if (f_cc < p.C2) { sbase = (const unsigned char*)p.src2; cs = p.C2; coff = f_cc; }
+      else { sbase = (const unsigned char*)p.src3; cs = p.C3; coff = f_cc - p.C2; }
+    } else if (f_cc < p.C0) { sbase = (const unsigned char*)p.src0; cs = p.C0; coff = f_cc; }
     else { sbase = (const unsigned char*)p.src1; cs = p.C1; coff = f_cc - p.C0; }
 #pragma unroll
     for (int i = 0; i < XG; ++i) {
@@ -340,8 +351,12 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LDR) * 64, (WAVES_M * WAVES_N 
       if (++f_tap == 9) { f_tap = 0; f_cc += BKE; need_setup = (f_cc == p.C0); }
     } else {
       f_cc += BKE;
-      if (f_cc == Ctot) { f_cc = 0; ++f_tap; }
-      need_setup = (f_cc == 0) | (f_cc == p.C0);
+      if (XT && f_tap == 9) {
+        need_setup = (f_cc == p.C2);             // switch to the second tensor of the extra tap
+      } else {
+        if (f_cc == Ctot) { f_cc = 0; ++f_tap; }
+        need_setup = (f_cc == 0) | (f_cc == p.C0);
+      }
     }
     return true;
   };
@@ -1050,7 +1065,7 @@ const TunedEntry* tuned_lookup(const IgemmParams& p, int dtype) {
   return nullptr;
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int NST = 2, bool PIPE = false, int LDR = 0, bool LNF = false, bool CM = false>
+template <typename T, int BM, int BN, int WM, int WN, int NST = 2, bool PIPE = false, int LDR = 0, bool LNF = false, bool CM = false, bool XT = false>
 int run(const IgemmParams& pin, hipStream_t s) {
   IgemmParams p = pin;
   p.dbg = g_dbg;
@@ -1071,7 +1086,7 @@ int run(const IgemmParams& pin, hipStream_t s) {
   const int grid_x = nwork < resident ? nwork : resident;
   const size_t lds = (size_t)NST * (BM + BN) * kRowBytes +
                      (epi_stage_dedicated<BM, BN, WM, WN>() ? epi_stage_bytes<BM, BN, WM, WN>() : 0);
-  auto kern = igemm_kernel<T, BM, BN, WM, WN, NST, PIPE, LDR, LNF, CM>;
+  auto kern = igemm_kernel<T, BM, BN, WM, WN, NST, PIPE, LDR, LNF, CM, XT>;
   static bool attr_set[kMaxDev] = {};
   const int dev = cur_dev();
   if (!attr_set[dev]) {
@@ -1079,7 +1094,7 @@ int run(const IgemmParams& pin, hipStream_t s) {
     attr_set[dev] = true;
   }
   g_last = IgemmDispatch{(int)sizeof(T) == 2 ? DT_BF16 : DT_F32, BM, BN, WM, WN, NST, PIPE ? 1 : 0, LDR,
-                         p.splits > 1 ? p.splits : 1, grid_x, LNF ? 1 : 0, CM ? 1 : 0};
+                         p.splits > 1 ? p.splits : 1, grid_x, LNF ? 1 : 0, CM ? 1 : 0, 0, XT ? 1 : 0};
   if (g_log_on) g_log.insert(igemm_dispatch_name(g_last));
   hipLaunchKernelGGL(kern, dim3(grid_x), dim3((WM * WN + LDR) * 64), lds, s, p);
   if (p.splits > 1 && !p.no_finish) {
@@ -1162,6 +1177,32 @@ int dispatch_ln(const IgemmParams& p, hipStream_t s) {
   return geglu ? run<T, 64, 128, 2, 2, 2, false, 0, true>(p, s) : run<T, 64, 160, 2, 2, 2, false, 0, true>(p, s);
 }
 
+int g_xt_mode = 1;               // igemm_set_xt_mode (debug key 19): 0 = engines keep conv_shortcut as a launch of its own
+
+// conv2 + conv_shortcut of a resnet as one launch (IgemmParams::src2 ...): the three tile forms the UNet's resnet convs use.
+// The launch table is consulted with the 3x3 part's K (tuned_lookup ignores the extra tap), so the launch inherits the entry
+// of the conv it extends.
+template <typename T>
+int dispatch_xt(const IgemmParams& p, hipStream_t s) {
+  if constexpr (sizeof(T) == 2) {
+    if (p.N % 160 != 0) return -2;
+    int cfg = -1;
+    if (const TunedEntry* e = tuned_lookup(p, DT_BF16)) cfg = e->cfg;
+    if (cfg != 0 && cfg != 3 && cfg != 4) {
+      const int sp = p.splits > 1 ? p.splits : 1;
+      const long t256 = (long)((p.M + 255) / 256) * (p.N / 160), t128 = (long)((p.M + 127) / 128) * (p.N / 160);
+      const int nk_slice = ((p.taps * (p.C0 + p.C1) + p.C2 + p.C3) / 64) / sp;
+      if (t256 >= 240) cfg = 0;
+      else if (mid8_ok(t128, sp)) cfg = nk_slice >= 40 ? 3 : 4;
+      else cfg = t256 * sp >= 160 ? 0 : 3;
+    }
+    if (cfg == 0) return run<T, 256, 160, 4, 2, 3, true, 4, false, false, true>(p, s);
+    if (cfg == 3) return run<T, 128, 160, 2, 2, 4, true, 4, false, false, true>(p, s);
+    return run<T, 128, 160, 4, 2, 3, true, 0, false, false, true>(p, s);
+  }
+  return -2;
+}
+
 // the split-K finish every kernel of the family shares (p.splits > 1, slabs written)
 template <typename T>
 int launch_finish(const IgemmParams& pin, hipStream_t s) {
@@ -1179,15 +1220,16 @@ template <typename T>
 int dispatch(const IgemmParams& p, hipStream_t s) {
   if constexpr (sizeof(T) == 2) {
     // small maps, long K: the weight-streaming kernel (igemm_ws.hip) writes the slabs
-    if (p.splits > 1 && g_big == kDefaultPolicy && g_force_cfg < 0 && igemm_ws_ok(p, DT_BF16)) {
+    if (p.splits > 1 && p.C2 == 0 && g_big == kDefaultPolicy && g_force_cfg < 0 && igemm_ws_ok(p, DT_BF16)) {
       const int r = launch_igemm_ws(p, s);
       if (r) return r;
       const int nw = igemm_ws_waves();
-      g_last = IgemmDispatch{DT_BF16, 128, 32 * nw, 1, nw, 4, 1, 0, p.splits, ((p.M + 127) / 128) * (p.N / (32 * nw)) * p.splits, 0, 0, nw};
+      g_last = IgemmDispatch{DT_BF16, 128, 32 * nw, 1, nw, 4, 1, 0, p.splits, ((p.M + 127) / 128) * (p.N / (32 * nw)) * p.splits, 0, 0, nw, 0};
       if (g_log_on) g_log.insert(igemm_dispatch_name(g_last));
       return p.no_finish ? 0 : launch_finish<T>(p, s);
     }
   }
+  if (p.C2 > 0) return dispatch_xt<T>(p, s);
   if (p.cm) {   // channel-major 3x3 conv: one instantiation (the 256-row loader-wave tile the large maps use anyway), bf16 only
     if constexpr (sizeof(T) == 2) {
       if (!p.rowstats && p.epi == EPI_STORE && p.N % 160 == 0) return run<T, 256, 160, 4, 2, 3, true, 4, false, true>(p, s);
@@ -1293,7 +1335,7 @@ std::string igemm_dispatch_name(const IgemmDispatch& d) {
     return buf;
   }
   std::snprintf(buf, sizeof buf, "igemm<%s,%d,%d,%d,%d,%d,%d,%d%s%s>%s", d.dtype == DT_BF16 ? "bf16" : "f32", d.bm, d.bn, d.wm, d.wn,
-                d.nst, d.pipe, d.ldr, d.lnf ? ",ln" : "", d.cm ? ",cm" : "", d.splits > 1 ? "/splitk" : "");
+                d.nst, d.pipe, d.ldr, d.lnf ? ",ln" : "", d.cm ? ",cm" : (d.xt ? ",xt" : ""), d.splits > 1 ? "/splitk" : "");
   return buf;
 }
 void igemm_log_enable(int on) { g_log_on = on != 0; if (on) g_log.clear(); }
@@ -1316,7 +1358,7 @@ int igemm_pick_bn(int n_real, int epi) {
 // returns the number of K slices (1 = no split).  Mirrors dispatch()'s tile choice.
 int igemm_plan_splits(const IgemmParams& p, int dtype) {
   if (p.epi != EPI_STORE || p.rowstats) return 1;
-  if (g_big == kDefaultPolicy && g_force_cfg < 0 && igemm_ws_ok(p, dtype)) return igemm_ws_splits(p);
+  if (p.C2 == 0 && g_big == kDefaultPolicy && g_force_cfg < 0 && igemm_ws_ok(p, dtype)) return igemm_ws_splits(p);
   if (const TunedEntry* e = tuned_lookup(p, dtype)) return e->splits;
   const int bke = dtype == DT_BF16 ? 64 : 32;
   const int bn = p.N % 160 == 0 ? 160 : (p.N % 128 == 0 ? 128 : (p.N % 64 == 0 ? 64 : 32));
@@ -1345,6 +1387,67 @@ size_t igemm_partial_bytes(const IgemmParams& p) {
   return p.splits > 1 ? (size_t)p.splits * p.M * p.N * sizeof(float) : 0;
 }
 
+void igemm_set_xt_mode(int on) { g_xt_mode = on ? 1 : 0; }
+int igemm_get_xt_mode() { return g_xt_mode; }
+bool igemm_xt_ok(const IgemmParams& p, int dtype) {
+  return g_xt_mode && dtype == DT_BF16 && p.C2 > 0 && p.src2 && p.C2 % 64 == 0 && p.C3 % 64 == 0 && (p.C3 == 0 || p.src3) && p.taps == 9 && p.stride == 1 &&
+         !p.up && !p.cm && (p.pad < 0 || p.pad == 1) && p.N % 160 == 0 && p.epi == EPI_STORE && !p.rowstats && g_big == kDefaultPolicy &&
+         g_force_cfg < 0;
+}
+
+namespace {
+template <typename T>
+__global__ void concat_rows_kernel(const T* a, int K1, const T* b, int K2, T* out, size_t total) {
+  const int K = K1 + K2;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t n = i / K;
+    const int k = (int)(i - n * K);
+    out[i] = k < K1 ? a[n * K1 + k] : b[n * K2 + (k - K1)];
+  }
+}
+}  // namespace
+namespace {
+__global__ void vec_add_kernel(const float* a, const float* b, float* out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = a[i] + b[i];
+}
+}  // namespace
+namespace {
+__global__ void chain_weights_kernel(const float* __restrict__ wp, const float* __restrict__ w2, const float* __restrict__ b2,
+                                     const float* __restrict__ bp, float* __restrict__ wcat, float* __restrict__ bcat, int C) {
+  const int n = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x, K4 = 4 * C;
+  if (k < K4) {
+    float acc = 0.f;
+    for (int j = 0; j < C; ++j) acc = fmaf(wp[(size_t)n * C + j], w2[(size_t)j * K4 + k], acc);
+    wcat[(size_t)n * (5 * C) + k] = acc;
+  } else if (k < 5 * C) {
+    wcat[(size_t)n * (5 * C) + k] = wp[(size_t)n * C + (k - K4)];
+  }
+  if (k == 0) {
+    float acc = bp ? bp[n] : 0.f;
+    if (b2)
+      for (int j = 0; j < C; ++j) acc = fmaf(wp[(size_t)n * C + j], b2[j], acc);
+    bcat[n] = acc;
+  }
+}
+}  // namespace
+int launch_chain_weights(const float* wp, const float* w2, const float* b2, const float* bp, float* wcat, float* bcat, int C, hipStream_t s) {
+  hipLaunchKernelGGL(chain_weights_kernel, dim3((5 * C + 255) / 256, C), dim3(256), 0, s, wp, w2, b2, bp, wcat, bcat, C);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+int launch_vec_add(const float* a, const float* b, float* out, int n, hipStream_t s) {
+  hipLaunchKernelGGL(vec_add_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a, b, out, n);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+int launch_concat_rows(const void* a, int K1, const void* b, int K2, void* out, int N, int dtype, hipStream_t s) {
+  const size_t total = (size_t)N * (K1 + K2);
+  const size_t blocks = (total + 255) / 256;
+  const unsigned g = (unsigned)(blocks < 16384 ? blocks : 16384);
+  if (dtype == DT_BF16) hipLaunchKernelGGL(concat_rows_kernel<bf16_t>, dim3(g), dim3(256), 0, s, (const bf16_t*)a, K1, (const bf16_t*)b, K2, (bf16_t*)out, total);
+  else hipLaunchKernelGGL(concat_rows_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)a, K1, (const float*)b, K2, (float*)out, total);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
 void igemm_set_cm_mode(int mode) { g_cm_mode = mode < -1 || mode > 1 ? -1 : mode; }
 int igemm_get_cm_mode() { return g_cm_mode; }
 bool igemm_conv_cm(int hw, int ctot, int n, int k, int stride, int up, int dtype) {
@@ -1362,6 +1465,7 @@ int launch_igemm(const IgemmParams& p, int dtype, hipStream_t s) {
   if (p.epi == EPI_GEGLU && p.N % 128 != 0) return -2;
   if (p.splits > 1 && (p.epi != EPI_STORE || p.partial == nullptr)) return -2;
   if (p.rowstats && (!p.c1 || p.rowbias || p.splits > 1 || (p.epi != EPI_STORE && p.epi != EPI_GEGLU))) return -2;
+  if ((p.C2 > 0 || p.C3 > 0) && !igemm_xt_ok(p, dtype)) return -2;
   return dtype == DT_BF16 ? dispatch<bf16_t>(p, s) : dispatch<float>(p, s);
 }
 

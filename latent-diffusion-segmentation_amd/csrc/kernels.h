@@ -44,6 +44,13 @@ struct IgemmParams {
   const void* src0 = nullptr;  // [B, Hi*Wi, C0]
   const void* src1 = nullptr;  // [B, Hi*Wi, C1]  channel-concat partner (torch.cat([h, skip],1))
   int C0 = 0, C1 = 0;
+  // Extra centre tap (round 5): K continues past the 3x3 taps with C2 (+ C3) channels of a THIRD (and fourth) tensor read at the
+  // output pixel itself - a 1x1 conv over torch.cat([src2, src3], 1) accumulated into the same tile.  The resnet's
+  // conv_shortcut(x) + conv2(h) of diffusers' ResnetBlock2D as ONE launch: W rows are [9 * (C0 + C1) | C2 + C3], bias = b2 + bs.
+  // 3x3, stride 1, no upsample, tap-major K, bf16 only (launch_igemm checks).
+  const void* src2 = nullptr;
+  const void* src3 = nullptr;
+  int C2 = 0, C3 = 0;
   int B = 0, Hi = 0, Wi = 0, Ho = 0, Wo = 0;
   int taps = 1;     // 1 (1x1 conv / Linear) or 9 (3x3, pad 1)
   int pad = -1;     // top/left zero padding of a 3x3 conv; -1 = 1.  0 with stride 2 = F.pad(x,(0,1,0,1)) + conv(pad 0)
@@ -102,11 +109,20 @@ void ops_bench_knob(int key, int value);   // ldmseg_bench_igemm (ops_api.hip): 
 void igemm_set_cm_mode(int mode);
 int igemm_get_cm_mode();
 bool igemm_conv_cm(int hw, int ctot, int n, int k, int stride, int up, int dtype);
+bool igemm_xt_ok(const IgemmParams& p, int dtype);   // the launch (with src2 / C2 set) has an extra-tap instantiation and key 19 allows it
+void igemm_set_xt_mode(int on);
+int igemm_get_xt_mode();
+// out[n][0:K1] = a[n][:], out[n][K1:K1+K2] = b[n][:]  (rows of two packed weight matrices side by side), compute dtype
+// Weights of two chained Linear layers with nothing in between, y = Wp (W2 g + b2 + h) + bp = [Wp W2 | Wp] [g | h] + (bp + Wp b2):
+// wcat [C][5C] fp32 = [Wp W2 | Wp], bcat [C] = bp + Wp b2 (wp [C][C], w2 [C][4C]; fp32 products, create time only)
+int launch_chain_weights(const float* wp, const float* w2, const float* b2, const float* bp, float* wcat, float* bcat, int C, hipStream_t s);
+int launch_vec_add(const float* a, const float* b, float* out, int n, hipStream_t s);
+int launch_concat_rows(const void* a, int K1, const void* b, int K2, void* out, int N, int dtype, hipStream_t s);
 void igemm_force_cfg(int cfg);   // tuning tool: >= 0 runs every launch with that entry of the instantiation list, -1 = off
 int igemm_get_dbg();       // current (policy << 8) | ablation flags
 int igemm_default_dbg();   // the shipped value
 // template instantiation + plan of the most recent launch_igemm (test introspection)
-struct IgemmDispatch { int dtype, bm, bn, wm, wn, nst, pipe, ldr, splits, grid, lnf, cm, ws; };   // ws: waves of igemm_ws_kernel (0: igemm_kernel)
+struct IgemmDispatch { int dtype, bm, bn, wm, wn, nst, pipe, ldr, splits, grid, lnf, cm, ws, xt; };   // ws: waves of igemm_ws_kernel (0: igemm_kernel)
 IgemmDispatch igemm_last_dispatch();
 std::string igemm_dispatch_name(const IgemmDispatch& d);
 void igemm_log_enable(int on);      // start (and clear) / stop recording the distinct instantiations launched

@@ -453,6 +453,64 @@ static int op_igemm_impl(const float* x, const float* x2, const float* w, const 
   return unpack_nhwc(op, out, B, cout, Ho * Wo, cout, dtype, s);
 }
 
+// conv2d(h, w2, b2, padding=1) + conv2d(cat([xs, xs2], 1), ws, bs) - the tail of a diffusers ResnetBlock2D with a conv_shortcut -
+// as the engine runs it in bf16: ONE implicit-GEMM launch whose K range continues past the nine taps with the shortcut's input
+// channels read at the output pixel (IgemmParams::src2 / src3).  xs2 may be NULL (Cs2 = 0).  iters > 0: timing like
+// ldmseg_bench_igemm (average microseconds per launch incl. the split-K finish).  Returns -4 when the shape has no such launch.
+int ldmseg_op_conv3x3_plus_1x1(const float* h, const float* w2, const float* b2, const float* xs, const float* xs2, const float* ws,
+                               const float* bs, int B, int C, int Cs, int Cs2, int H, int W, int Co, int splits, int dtype, float* out,
+                               int iters, float* us_per_launch, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  Temp t;
+  if (dtype != DT_BF16 || C % 64 || Cs % 64 || Cs2 % 64 || !h || !w2 || !xs || !ws) return -2;
+  const int HW = H * W, cs = Cs + Cs2;
+  void* hp = t.get((size_t)B * HW * C * 2);
+  void* xp = t.get((size_t)B * HW * Cs * 2);
+  void* x2p = Cs2 ? t.get((size_t)B * HW * Cs2 * 2) : nullptr;
+  if (launch_pack_nchw(h, hp, B, C, HW, C, 1.f, 0.f, dtype, s)) return -3;
+  if (launch_pack_nchw(xs, xp, B, Cs, HW, Cs, 1.f, 0.f, dtype, s)) return -3;
+  if (Cs2 && launch_pack_nchw(xs2, x2p, B, Cs2, HW, Cs2, 1.f, 0.f, dtype, s)) return -3;
+  const int Np = rupi(Co, igemm_pick_bn(Co, EPI_STORE));
+  void* w2p = t.get((size_t)Np * 9 * C * 2);
+  void* wsp = t.get((size_t)Np * cs * 2);
+  void* wx = t.get((size_t)Np * (9 * C + cs) * 2);
+  if (launch_repack_conv(w2, w2p, Co, C, 3, 3, Np, C, dtype, s)) return -3;
+  if (launch_repack_conv(ws, wsp, Co, cs, 1, 1, Np, cs, dtype, s)) return -3;
+  if (launch_concat_rows(w2p, 9 * C, wsp, cs, wx, Np, dtype, s)) return -3;
+  float* b2p = (float*)t.get(Np * sizeof(float));
+  float* bsp = (float*)t.get(Np * sizeof(float));
+  float* bx = (float*)t.get(Np * sizeof(float));
+  (void)hipMemsetAsync(b2p, 0, Np * sizeof(float), s);
+  (void)hipMemsetAsync(bsp, 0, Np * sizeof(float), s);
+  if (b2) (void)hipMemcpyAsync(b2p, b2, Co * sizeof(float), hipMemcpyDeviceToDevice, s);
+  if (bs) (void)hipMemcpyAsync(bsp, bs, Co * sizeof(float), hipMemcpyDeviceToDevice, s);
+  if (launch_vec_add(b2p, bsp, bx, Np, s)) return -3;
+  void* op = t.get((size_t)B * HW * Co * 2);
+  IgemmParams p;
+  p.src0 = hp; p.C0 = C; p.src2 = xp; p.C2 = Cs; p.src3 = x2p; p.C3 = Cs2;
+  p.B = B; p.Hi = p.Ho = H; p.Wi = p.Wo = W; p.taps = 9; p.stride = 1;
+  p.M = B * HW; p.N = Np; p.n_valid = Co; p.W = wx; p.bias = bx; p.out = op; p.ldo = Co; p.epi = EPI_STORE;
+  if (!igemm_xt_ok(p, dtype)) return -4;
+  const int sp = splits > 0 ? splits : igemm_plan_splits(p, dtype);
+  if (sp > 1) { p.splits = sp; p.partial = (float*)t.get((size_t)sp * p.M * Np * sizeof(float)); }
+  const int r = launch_igemm(p, dtype, s);
+  if (r) return r;
+  if (iters > 0 && us_per_launch) {
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, s);
+    for (int i = 0; i < iters; ++i) (void)launch_igemm(p, dtype, s);
+    (void)hipEventRecord(e1, s);
+    (void)hipEventSynchronize(e1);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    *us_per_launch = 1e3f * ms / iters;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  }
+  if (!out) return 0;
+  return unpack_nhwc(op, out, B, Co, HW, Co, dtype, s);
+}
+
 // q[i] = n[i] / d through the multiply-shift divisor the kernels use (FastDiv, kernels.h): exactness test hook
 int ldmseg_op_fastdiv(const int* n, int count, int d, int* q, void* stream) {
   if (!n || !q || count < 0 || d < 1) return -2;

@@ -90,6 +90,7 @@ SIGNATURES = {
     "ldmseg_op_convt2": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "ldmseg_op_bilinear2x": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "ldmseg_op_igemm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "ldmseg_op_conv3x3_plus_1x1": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, C.POINTER(C.c_float), _vp]),
     "ldmseg_op_ln_linear": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _i, _vp, _vp]),
     "ldmseg_op_conv_out_tail": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, C.POINTER(C.c_float), _i, _i, _f, _vp, _vp, _vp, _vp, _vp,
                                      _vp, _f, _f, _vp, _vp]),

@@ -29,6 +29,8 @@ def L():
     from ldmseg_amd import _lib
     assert _lib.lib().ldmseg_debug_get(1) == _lib.lib().ldmseg_debug_get(-1), "a previous test leaked a tile policy"
     assert _lib.lib().ldmseg_debug_get(12) == 3 and _lib.lib().ldmseg_debug_get(14) == 3, "a previous test leaked a fused-kernel switch"
+    assert _lib.lib().ldmseg_debug_get(19) == 1 and _lib.lib().ldmseg_debug_get(17) == 0 and _lib.lib().ldmseg_debug_get(20) == 1, \
+        "a previous test leaked a GEMM-path switch"
     return _lib
 
 
@@ -73,6 +75,7 @@ SHAPES = [
     (32, 640, 0, 1920, 1, 1, 0, 0, 0, 0),
     (32, 640, 0, 5120, 1, 1, 0, 1, 0, 0),
     (32, 2560, 0, 640, 1, 1, 0, 0, 1, 0),
+    (32, 2560, 640, 640, 1, 1, 0, 0, 1, 0),   # ff.net.2 + proj_out chained into one Linear over cat([g, h]) (+ x) - round 5
     (32, 320, 0, 640, 1, 1, 0, 0, 0, 0),
     (32, 1280, 640, 640, 1, 1, 0, 0, 0, 0),
     (32, 640, 640, 640, 1, 1, 0, 0, 0, 0),
@@ -89,6 +92,7 @@ SHAPES = [
     (16, 1280, 0, 3840, 1, 1, 0, 0, 0, 0),
     (16, 1280, 0, 10240, 1, 1, 0, 1, 0, 0),
     (16, 5120, 0, 1280, 1, 1, 0, 0, 1, 0),
+    (16, 5120, 1280, 1280, 1, 1, 0, 0, 1, 0),  # chained ff.net.2 + proj_out
     (16, 640, 0, 1280, 1, 1, 0, 0, 0, 0),
     (16, 1280, 1280, 1280, 1, 1, 0, 0, 0, 0),
     (16, 1280, 640, 1280, 1, 1, 0, 0, 0, 0),
@@ -102,6 +106,7 @@ SHAPES = [
     (8, 1280, 0, 3840, 1, 1, 0, 0, 0, 0),
     (8, 1280, 0, 10240, 1, 1, 0, 1, 0, 0),
     (8, 5120, 0, 1280, 1, 1, 0, 0, 1, 0),
+    (8, 5120, 1280, 1280, 1, 1, 0, 0, 1, 0),   # chained ff.net.2 + proj_out
     (8, 1280, 1280, 1280, 1, 1, 0, 0, 0, 0),
 ]
 
@@ -208,6 +213,47 @@ def test_conv_out_shape_vs_oracle(L, dt, cfg):
         torch.cuda.synchronize()
         assert rel_err(out2, ref) < 1e-3
         SEEN[(cfg, dt)].add("conv_out_tail<bf16>")
+
+
+# conv2 + conv_shortcut of the resnets whose input and output channel counts differ, as the bf16 forward runs them (round 5):
+# ONE launch, K = 9 * C + Cs + Cs2.  (H at L = 64, C = cout, Cs = hidden channels, Cs2 = skip channels of torch.cat([h, skip], 1))
+XT_SHAPES = [
+    (64, 320, 640, 320), (64, 320, 320, 320),                                           # up_blocks.3
+    (32, 640, 1280, 640), (32, 640, 640, 640), (32, 640, 640, 320), (32, 640, 320, 0),  # up_blocks.2, down_blocks.1.resnets.0
+    (16, 1280, 1280, 1280), (16, 1280, 1280, 640), (16, 1280, 640, 0),                  # up_blocks.1, down_blocks.2.resnets.0
+    (8, 1280, 1280, 1280),                                                              # up_blocks.0
+]
+
+
+@pytest.mark.parametrize("cfg", CONFIGS, ids=CFG_IDS)
+@pytest.mark.parametrize("case", XT_SHAPES)
+def test_resnet_tail_one_launch_vs_oracle(L, cfg, case):
+    """F.conv2d(h, w2, b2, padding=1) + F.conv2d(cat([x, skip]), ws, bs) (diffusers ResnetBlock2D: conv2 + conv_shortcut) against the
+    engine's single extra-tap launch at the configuration's shapes; records the ',xt' instantiation that ran."""
+    import ctypes as C
+    H, Cc, Cs, Cs2 = case
+    B, lat = cfg
+    H = H * lat // 64
+    torch.set_num_threads(64)
+    g = torch.Generator().manual_seed(hash(case) & 0xffff)
+    h = torch.randn(B, Cc, H, H, generator=g)
+    xs = torch.randn(B, Cs, H, H, generator=g)
+    xs2 = torch.randn(B, Cs2, H, H, generator=g) if Cs2 else None
+    w2 = torch.randn(Cc, Cc, 3, 3, generator=g) / (9 * Cc) ** 0.5
+    ws = torch.randn(Cc, Cs + Cs2, 1, 1, generator=g) / (Cs + Cs2) ** 0.5
+    b2, bs = torch.randn(Cc, generator=g), torch.randn(Cc, generator=g)
+    xin = torch.cat([xs, xs2], 1) if Cs2 else xs
+    ref = F.conv2d(bf16_round(h), bf16_round(w2), b2, padding=1) + F.conv2d(bf16_round(xin), bf16_round(ws), bs)
+    out = torch.empty(ref.shape, device="cuda")
+    dh, dxs, dxs2, dw2, dws, db2, dbs = dev(h), dev(xs), dev(xs2), dev(w2), dev(ws), dev(b2), dev(bs)
+    r = L.lib().ldmseg_op_conv3x3_plus_1x1(P(dh), P(dw2), P(db2), P(dxs), P(dxs2), P(dws), P(dbs), B, Cc, Cs, Cs2, H, H, Cc, 0, BF16,
+                                           P(out), 0, None, None)
+    assert r == 0, (r, L.lib().ldmseg_last_error())
+    torch.cuda.synchronize()
+    name = L.igemm_last_kernel()
+    assert ",xt" in name, name
+    SEEN[(cfg, BF16)].add(name.split(" ")[0])
+    assert rel_err(out, ref) < 8e-3, (cfg, case, name)
 
 
 @pytest.mark.parametrize("cfg", CONFIGS, ids=CFG_IDS)

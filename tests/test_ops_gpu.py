@@ -1119,3 +1119,48 @@ def test_split_bf16_layernorm_folded_gemm(L, M, K, N, geglu):
     name = L.igemm_last_kernel()
     assert ",ln" in name and name.startswith("igemm<f32,"), name
     assert rel_err(out, y) < 2e-4, name
+
+
+# ---- resnet tail as one launch: conv2 + conv_shortcut through an extra centre tap (igemm.hip XT, round 5) ----
+# (B, H, W, C = cout, Cs, Cs2, splits)
+XT_CASES = {
+    "plain": (2, 16, 16, 320, 640, 0, 0),
+    "concat": (2, 16, 16, 320, 640, 320, 0),             # shortcut over torch.cat([h, skip]): the extra tap switches tensors
+    "ragged": (3, 5, 7, 320, 64, 128, 0),                # M = 105: rows past M, images end inside tiles, every row has padding taps
+    "slices3": (1, 8, 8, 320, 192, 0, 3),                # 45 + 3 K tiles over 3 slices of 16: the extra tap is the tail of the last slice
+    "slices7": (2, 8, 8, 640, 640, 640, 7),              # 110 K tiles over 7 slices: one slice starts inside the extra tap
+    "big_tile": (8, 64, 64, 320, 320, 320, 0),           # the 256 x 160 loader-wave form of the 64 x 64 level
+}
+
+
+@pytest.mark.parametrize("case", sorted(XT_CASES))
+def test_resnet_tail_extra_tap(L, case):
+    """conv2(h) + conv_shortcut(cat([x, skip])) as ONE implicit GEMM whose K range runs on past the nine taps (IgemmParams::src2):
+    against the two torch convs on the bf16-rounded operands, on shapes that hit the edges of the extra segment."""
+    B, H, W, Cc, Cs, Cs2, splits = XT_CASES[case]
+    g = torch.Generator().manual_seed(len(case) * 17 + Cs)
+    h = torch.randn(B, Cc, H, W, generator=g)
+    xs = torch.randn(B, Cs, H, W, generator=g)
+    xs2 = torch.randn(B, Cs2, H, W, generator=g) if Cs2 else None
+    w2 = torch.randn(Cc, Cc, 3, 3, generator=g) / (9 * Cc) ** 0.5
+    ws = torch.randn(Cc, Cs + Cs2, 1, 1, generator=g) / (Cs + Cs2) ** 0.5
+    b2, bs = torch.randn(Cc, generator=g), torch.randn(Cc, generator=g)
+    xin = torch.cat([xs, xs2], 1) if Cs2 else xs
+    ref = F.conv2d(bf16_round(h), bf16_round(w2), b2, padding=1) + F.conv2d(bf16_round(xin), bf16_round(ws), bs)
+    out = torch.empty(ref.shape, device="cuda")
+    dh, dxs, dxs2, dw2, dws, db2, dbs = dev(h), dev(xs), dev(xs2), dev(w2), dev(ws), dev(b2), dev(bs)
+    r = L.lib().ldmseg_op_conv3x3_plus_1x1(P(dh), P(dw2), P(db2), P(dxs), P(dxs2), P(dws), P(dbs), B, Cc, Cs, Cs2, H, W, Cc, splits, BF16,
+                                           P(out), 0, None, None)
+    assert r == 0, (r, L.lib().ldmseg_last_error())
+    torch.cuda.synchronize()
+    name = L.igemm_last_kernel()
+    assert ",xt" in name, name
+    assert rel_err(out, ref) < 8e-3, (case, name)
+    # the switch (debug key 19) makes the engine keep the two launches: the operator then says so
+    lib = L.lib()
+    try:
+        lib.ldmseg_debug_set(19, 0)
+        assert lib.ldmseg_op_conv3x3_plus_1x1(P(dh), P(dw2), P(db2), P(dxs), P(dxs2), P(dws), P(dbs), B, Cc, Cs, Cs2, H, W, Cc, splits, BF16,
+                                              P(out), 0, None, None) == -4
+    finally:
+        lib.ldmseg_debug_set(19, 1)
