@@ -298,9 +298,10 @@ int ldmseg_profile_dump(const char* path);
  * whole-k-group X buffers with a 3-slot ring), bits 8-19 largest M / 4, bits 20-27 fewest K tiles; default 0 = off (measured level
  * with igemm_kernel); must be set BEFORE a handle is created (the handle then holds the fragment-major weight packing);
  * key 19 = resnet conv2 + conv_shortcut as one launch with an extra centre tap (bf16; default 1, 0 = two launches);
- * key 20 = ff.net.2 and proj_out of the 640- / 1280-channel transformers as one chained Linear over [g | h] (bf16; default 1). */
+ * key 20 = ff.net.2 and proj_out of the 640- / 1280-channel transformers as one chained Linear over [g | h] (bf16; default 1);
+ * key 21 = upsampler convs (nearest x2 -> conv3x3) as four 2x2-tap phase convs on the low-resolution map (bf16; default 1). */
 int ldmseg_debug_set(int key, int value);
-/* current value of a knob (keys 1, 9, 12, 14, 15, 16, 17, 19, 20); key -1 = the shipped default of key 1.  Tests restore through this, never a literal.
+/* current value of a knob (keys 1, 9, 12, 14, 15, 16, 17, 19, 20, 21); key -1 = the shipped default of key 1.  Tests restore through this, never a literal.
  * key 10 = number of cooperative-GroupNorm workgroups that took the self-computing path in ldmseg_op_* launches so far. */
 int ldmseg_debug_get(int key);
 

@@ -194,6 +194,7 @@ struct ConvW {
   float* c1 = nullptr;    // [N] row sums of w when a LayerNorm is folded into this GEMM (IgemmParams::c1), else null
   int N = 0, n_valid = 0, cin_pad = 0, taps = 1, cout = 0;
   void* w_cm = nullptr;   // 3x3 layers that may run on large maps: second packing in channel-major K order (IgemmParams::cm)
+  void* w_up4 = nullptr;  // upsampler convs, bf16: [4 phases][N][2x2 taps][C] with the 3x3 taps pre-summed per phase (IgemmParams::up4)
   void* w_ws = nullptr;   // wide layers with long K: third packing, fragment-major (IgemmParams::Wf, igemm_ws.hip) - small maps
 };
 struct NormW { float* g = nullptr; float* b = nullptr; int C = 0; };
@@ -330,6 +331,20 @@ struct Exec {
            const float* rowbias, int rb_stride, const Act* resid, int silu = 0, int pad = -1) {
     const int ctot = x.C + (x2 ? x2->C : 0);
     if (ctot != w.cin_pad) return fail(LDMSEG_E_SHAPE, "conv: channel mismatch");
+    if (up && w.w_up4 && w.taps == 9 && stride == 1 && !x2 && !resid && !rowbias && !silu && pad < 0 &&
+        igemm_up4_ok(B, x.H, x.W, x.C, w.N, dt)) {
+      // conv3x3(nearest_x2(x)) as four 2x2 phase convs on the low-resolution map: 4 B H W virtual rows, K = 4 C
+      *out = new_act(w.n_valid, 2 * x.H, 2 * x.W, persist);
+      IgemmParams p;
+      p.src0 = x.p; p.C0 = x.C;
+      p.B = B; p.Hi = p.Ho = x.H; p.Wi = p.Wo = x.W;
+      p.taps = 4; p.stride = 1; p.up4 = 1;
+      p.M = 4 * B * x.H * x.W; p.N = w.N; p.n_valid = w.n_valid;
+      p.W = w.w_up4; p.bias = w.bias;
+      p.out = out->p; p.ldo = w.n_valid;
+      p.epi = EPI_STORE;
+      return igemm(p);
+    }
     const int Hl = up ? 2 * x.H : x.H, Wl = up ? 2 * x.W : x.W;
     // stride 2: pad 1 both sides (UNet downsample_padding=1) or pad 0 + one zero row/column at the bottom/right
     const int Ho = (w.taps == 9 && stride == 2) ? (pad == 0 ? Hl / 2 : (Hl - 1) / 2 + 1) : Hl;
@@ -713,7 +728,19 @@ int unet_build(ldmseg_unet* u, const WeightMap& wm) {
       c = co;
       if (i > 0) TRY(build_transformer(b, p + ".attentions." + std::to_string(j) + ".", c, &u->up_attn[i][j]));
     }
-    if (i < 3) TRY(b.conv("up_blocks." + std::to_string(i) + ".upsamplers.0.conv", c, c, 3, c, &u->up_conv[i]));
+    if (i < 3) {
+      const std::string key = "up_blocks." + std::to_string(i) + ".upsamplers.0.conv";
+      TRY(b.conv(key, c, c, 3, c, &u->up_conv[i]));
+      // Upsample2D = nearest x2 then this conv: an output pixel sees only 2 x 2 distinct source pixels, so the conv runs as four
+      // 2x2-tap phase convs on the low-resolution map with pre-summed weights (K = 4 C instead of 9 C; igemm.hip UP4)
+      ConvW& cw = u->up_conv[i];
+      if (u->dt == DT_BF16 && cw.N % 160 == 0 && c % bke(u->dt) == 0) {
+        const float* wraw;
+        TRY(b.wm->get(key + ".weight", (int64_t)c * c * 9, &wraw));
+        TRY(b.arena->alloc(&cw.w_up4, (size_t)16 * cw.N * c * esize(u->dt)));
+        TRY(launch_pack_up4(wraw, cw.w_up4, c, c, cw.N, c, u->dt, b.s));
+      }
+    }
   }
   TRY(b.norm("conv_norm_out", c, &u->norm_out));
   TRY(b.conv("conv_out", 4, c, 3, c, &u->conv_out));
@@ -1895,6 +1922,7 @@ int ldmseg_debug_set(int key, int value) {
   if (key == 17) { igemm_ws_set_mode(value & 7, (value >> 8) & 0xfff ? ((value >> 8) & 0xfff) * 4 : 0, (value >> 20) & 0xff); ++g_plan_epoch; return 0; }
   if (key == 19) { igemm_set_xt_mode(value); ++g_plan_epoch; return 0; }   // 1 (default): resnet conv2 + conv_shortcut as one launch (bf16)
   if (key == 20) { g_ffp_mode = value ? 1 : 0; ++g_plan_epoch; return 0; }
+  if (key == 21) { igemm_set_up4_mode(value); ++g_plan_epoch; return 0; }   // 1 (default): upsampler convs as four 2x2 phase convs (bf16)
   if (key == 6 || key == 7) { ops_bench_knob(key, value); return 0; }   // ldmseg_bench_igemm: 6 = weight copies rotated, 7 = folded-LN launch
   static unsigned long long ts_ptr = 0;                // keys 3/4: low/high half of a device stamp buffer (ablate builds)
   if (key == 3) { ts_ptr = (ts_ptr & 0xffffffff00000000ull) | (unsigned)value; igemm_set_tsbuf((void*)(uintptr_t)ts_ptr); return 0; }
@@ -1913,6 +1941,7 @@ int ldmseg_debug_get(int key) {
   if (key == 17) return igemm_ws_get_mode();
   if (key == 19) return igemm_get_xt_mode();
   if (key == 20) return g_ffp_mode;
+  if (key == 21) return igemm_get_up4_mode();
   if (key == 10) { const long long n = gn_coop_fallbacks(nullptr); return n > 0x7fffffffll ? 0x7fffffff : (int)n; }   // ring regions (ldmseg_op_* launches)
   return 0;
 }

@@ -124,7 +124,9 @@ constexpr bool epi_stage_dedicated() { return epi_stage_bytes<BM, BN, WAVES_M, W
 // CM: channel-major K order of a 3x3 conv (IgemmParams::cm).  A separate instantiation as well: carried as a run-time
 // branch it cost every launch of the family 2-5 % (measured; scalar registers and code in the K loop's DMA step).
 // XT: the launch carries an extra centre tap (IgemmParams::src2 / C2 / src3 / C3).  A separate instantiation for the same reason.
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int NST, bool PIPE, int LDR, bool LNF, bool CM = false, bool XT = false>
+// UP4: conv3x3(nearest_x2(x)) as four 2x2-tap phase convs on the low-resolution map (IgemmParams::up4).  Separate as well.
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int NST, bool PIPE, int LDR, bool LNF, bool CM = false, bool XT = false,
+          bool UP4 = false>
 __global__ __launch_bounds__((WAVES_M * WAVES_N + LDR) * 64, (WAVES_M * WAVES_N + LDR) > 8 ? 3 : 2) void igemm_kernel(const IgemmParams p) {   // <=256 regs at 2 waves/SIMD; 12-wave workgroups (8 compute + 4 loader waves) need 3 per SIMD: <=168
   constexpr int NW = WAVES_M * WAVES_N;   // 4 waves (128-row tiles, 2 workgroups/CU) or 8 (256-row tiles)
   static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
@@ -173,6 +175,17 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LDR) * 64, (WAVES_M * WAVES_N 
   const int Wlog = p.up ? 2 * p.Wi : p.Wi;
   const int pad = (p.taps == 9) ? (p.pad >= 0 ? p.pad : 1) : 0;
   const int HWo = p.Ho * p.Wo;
+  // UP4: virtual row (phase, image, i, j) -> row (image, 2i + py, 2j + px) of the upsampled output
+  auto out_row = [&](int m) __attribute__((always_inline)) -> size_t {
+    if constexpr (UP4) {
+      const int ph = fd_div(m, p.fd_mphase), mr = m - ph * p.fd_mphase.d;
+      const int b = fd_div(mr, p.fd_hwo), rem = mr - b * HWo;
+      const int oy = fd_div(rem, p.fd_wo), ox = rem - oy * p.Wo;
+      return ((size_t)b * 2 * p.Ho + 2 * oy + (ph >> 1)) * (size_t)(2 * p.Wo) + 2 * ox + (ph & 1);
+    } else {
+      return (size_t)m;
+    }
+  };
 
   // ---- direct-to-LDS staging (global_load_lds_dwordx4): one wave instruction fills one 8-row
   // group (1 KiB, lane l -> row l>>3, physical chunk l&7).  The XOR swizzle therefore lives on the
@@ -217,22 +230,30 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LDR) * 64, (WAVES_M * WAVES_N 
   auto item_setup = [&]() __attribute__((always_inline)) {
     int m0, n0, z;
     item_range(f_item, m0, n0, z, f_kt, f_kend);
+    int ph = 0;                                           // UP4: phase (py, px) of this tile (tiles never straddle phases)
+    if constexpr (UP4) ph = fd_div(m0, p.fd_mphase);
 #pragma unroll
     for (int i = 0; i < XG; ++i) {
       const int m = m0 + (i * NLW + wave) * 8 + ld_r;
       if (m < p.M) {
-        const int b = fd_div(m, p.fd_hwo), rem = m - b * HWo;
+        const int mr = UP4 ? m - ph * p.fd_mphase.d : m;
+        const int b = fd_div(mr, p.fd_hwo), rem = mr - b * HWo;
         const int oy = fd_div(rem, p.fd_wo), ox = rem - oy * p.Wo;
         ri[i].pix_base = b * p.Hi * p.Wi;
-        ri[i].iy0 = oy * p.stride - pad;
-        ri[i].ix0 = ox * p.stride - pad;
+        if constexpr (UP4) {                              // window rows {i - 1, i} for py = 0, {i, i + 1} for py = 1
+          ri[i].iy0 = oy - 1 + (ph >> 1);
+          ri[i].ix0 = ox - 1 + (ph & 1);
+        } else {
+          ri[i].iy0 = oy * p.stride - pad;
+          ri[i].ix0 = ox * p.stride - pad;
+        }
       } else {
         ri[i].pix_base = 0;
         ri[i].iy0 = -(1 << 28);
         ri[i].ix0 = 0;
       }
     }
-    wtile0 = (const unsigned char*)p.W + (size_t)n0 * K * sizeof(T);
+    wtile0 = (const unsigned char*)p.W + ((size_t)n0 + (UP4 ? (size_t)ph * p.N : 0)) * K * sizeof(T);
     if constexpr (CM) {                                  // K order [channel tile][tap]: fd_tpt divides by 9
       const int ct = fd_div(f_kt, p.fd_tpt);
       f_tap = f_kt - ct * 9;
@@ -281,8 +302,8 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LDR) * 64, (WAVES_M * WAVES_N 
   // falls outside the image sit on the zero page with stride 0.
   auto seg_setup = [&]() __attribute__((always_inline)) {
     const bool xtap = XT && f_tap == 9;           // the extra tap reads the output pixel itself (window offset = pad)
-    const int ky = xtap ? pad : ((p.taps == 9) ? f_tap / 3 : 0);
-    const int kx = xtap ? pad : ((p.taps == 9) ? f_tap - ky * 3 : 0);
+    const int ky = UP4 ? (f_tap >> 1) : (xtap ? pad : ((p.taps == 9) ? f_tap / 3 : 0));
+    const int kx = UP4 ? (f_tap & 1) : (xtap ? pad : ((p.taps == 9) ? f_tap - ky * 3 : 0));
     const unsigned char* sbase;
     int cs, coff;
     if (xtap) {
@@ -508,7 +529,7 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LDR) * 64, (WAVES_M * WAVES_N 
 #pragma unroll
               for (int e = 0; e < E; ++e) v[e] = silu_f(v[e]);
             }
-            if (!DBG(p, 64)) *(uint4*)((T*)p.out + (size_t)m * p.ldo + n) = Chunk<T>::pack(v);
+            if (!DBG(p, 64)) *(uint4*)((T*)p.out + out_row(m) * p.ldo + n) = Chunk<T>::pack(v);
             else asm volatile("" ::"v"(v[0]), "v"(v[E - 1]));
           }
         }
@@ -991,7 +1012,14 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const IgemmParams p)
       for (int r = 0; r < 4; ++r) v[r] += to_f32<T>(rp[r]);
     }
     if (p.silu) for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
-    T* o = (T*)p.out + (size_t)m * p.ldo + n;
+    size_t orow = (size_t)m;
+    if (p.up4) {                                           // virtual row (phase, image, i, j) -> upsampled output row
+      const int ph = fd_div(m, p.fd_mphase), mr = m - ph * p.fd_mphase.d;
+      const int b = fd_div(mr, p.fd_hwo), rem = mr - b * (p.Ho * p.Wo);
+      const int oy = fd_div(rem, p.fd_wo), ox = rem - oy * p.Wo;
+      orow = ((size_t)b * 2 * p.Ho + 2 * oy + (ph >> 1)) * (size_t)(2 * p.Wo) + 2 * ox + (ph & 1);
+    }
+    T* o = (T*)p.out + orow * p.ldo + n;
     if constexpr (sizeof(T) == 2) {
       *(uint2*)o = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
     } else {
@@ -1065,7 +1093,8 @@ const TunedEntry* tuned_lookup(const IgemmParams& p, int dtype) {
   return nullptr;
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int NST = 2, bool PIPE = false, int LDR = 0, bool LNF = false, bool CM = false, bool XT = false>
+template <typename T, int BM, int BN, int WM, int WN, int NST = 2, bool PIPE = false, int LDR = 0, bool LNF = false, bool CM = false, bool XT = false,
+          bool UP4 = false>
 int run(const IgemmParams& pin, hipStream_t s) {
   IgemmParams p = pin;
   p.dbg = g_dbg;
@@ -1078,6 +1107,7 @@ int run(const IgemmParams& pin, hipStream_t s) {
   p.fd_nt = fastdiv_make(nt);
   p.fd_ntiles = fastdiv_make(mt * nt);
   p.fd_nsplit = fastdiv_make(p.splits > 1 ? p.splits : 1);
+  p.fd_mphase = fastdiv_make(p.up4 ? p.M / 4 : 1);
   p.fd_tpt = fastdiv_make(CM ? 9 : (p.C0 + p.C1) / (int)(kRowBytes / sizeof(T)));   // CM: K tiles per channel tile
   const int nwork = mt * nt * (p.splits > 1 ? p.splits : 1);
   // persistent grid: as many workgroups as fit on the chip at once (2 per CU for the 4-wave tiles,
@@ -1086,7 +1116,7 @@ int run(const IgemmParams& pin, hipStream_t s) {
   const int grid_x = nwork < resident ? nwork : resident;
   const size_t lds = (size_t)NST * (BM + BN) * kRowBytes +
                      (epi_stage_dedicated<BM, BN, WM, WN>() ? epi_stage_bytes<BM, BN, WM, WN>() : 0);
-  auto kern = igemm_kernel<T, BM, BN, WM, WN, NST, PIPE, LDR, LNF, CM, XT>;
+  auto kern = igemm_kernel<T, BM, BN, WM, WN, NST, PIPE, LDR, LNF, CM, XT, UP4>;
   static bool attr_set[kMaxDev] = {};
   const int dev = cur_dev();
   if (!attr_set[dev]) {
@@ -1094,7 +1124,7 @@ int run(const IgemmParams& pin, hipStream_t s) {
     attr_set[dev] = true;
   }
   g_last = IgemmDispatch{(int)sizeof(T) == 2 ? DT_BF16 : DT_F32, BM, BN, WM, WN, NST, PIPE ? 1 : 0, LDR,
-                         p.splits > 1 ? p.splits : 1, grid_x, LNF ? 1 : 0, CM ? 1 : 0, 0, XT ? 1 : 0};
+                         p.splits > 1 ? p.splits : 1, grid_x, LNF ? 1 : 0, CM ? 1 : 0, 0, XT ? 1 : 0, UP4 ? 1 : 0};
   if (g_log_on) g_log.insert(igemm_dispatch_name(g_last));
   hipLaunchKernelGGL(kern, dim3(grid_x), dim3((WM * WN + LDR) * 64), lds, s, p);
   if (p.splits > 1 && !p.no_finish) {
@@ -1208,6 +1238,8 @@ template <typename T>
 int launch_finish(const IgemmParams& pin, hipStream_t s) {
   IgemmParams p = pin;
   p.fd_hwo = fastdiv_make(p.Ho * p.Wo);
+  p.fd_wo = fastdiv_make(p.Wo);
+  p.fd_mphase = fastdiv_make(p.up4 ? p.M / 4 : 1);
   const int nq = p.n_valid >> 2;
   const int gx = (nq + 63) / 64;
   int gy = (p.M + 3) / 4;
@@ -1224,10 +1256,14 @@ int dispatch(const IgemmParams& p, hipStream_t s) {
       const int r = launch_igemm_ws(p, s);
       if (r) return r;
       const int nw = igemm_ws_waves();
-      g_last = IgemmDispatch{DT_BF16, 128, 32 * nw, 1, nw, 4, 1, 0, p.splits, ((p.M + 127) / 128) * (p.N / (32 * nw)) * p.splits, 0, 0, nw, 0};
+      g_last = IgemmDispatch{DT_BF16, 128, 32 * nw, 1, nw, 4, 1, 0, p.splits, ((p.M + 127) / 128) * (p.N / (32 * nw)) * p.splits, 0, 0, nw, 0, 0};
       if (g_log_on) g_log.insert(igemm_dispatch_name(g_last));
       return p.no_finish ? 0 : launch_finish<T>(p, s);
     }
+  }
+  if (p.up4) {                 // one tile form: 256 x 160 with loader waves (every up4 launch is >= 240 work items, K >= 20 tiles)
+    if constexpr (sizeof(T) == 2) return run<T, 256, 160, 4, 2, 3, true, 4, false, false, false, true>(p, s);
+    return -2;
   }
   if (p.C2 > 0) return dispatch_xt<T>(p, s);
   if (p.cm) {   // channel-major 3x3 conv: one instantiation (the 256-row loader-wave tile the large maps use anyway), bf16 only
@@ -1335,7 +1371,7 @@ std::string igemm_dispatch_name(const IgemmDispatch& d) {
     return buf;
   }
   std::snprintf(buf, sizeof buf, "igemm<%s,%d,%d,%d,%d,%d,%d,%d%s%s>%s", d.dtype == DT_BF16 ? "bf16" : "f32", d.bm, d.bn, d.wm, d.wn,
-                d.nst, d.pipe, d.ldr, d.lnf ? ",ln" : "", d.cm ? ",cm" : (d.xt ? ",xt" : ""), d.splits > 1 ? "/splitk" : "");
+                d.nst, d.pipe, d.ldr, d.lnf ? ",ln" : "", d.cm ? ",cm" : (d.xt ? ",xt" : (d.up4 ? ",up4" : "")), d.splits > 1 ? "/splitk" : "");
   return buf;
 }
 void igemm_log_enable(int on) { g_log_on = on != 0; if (on) g_log.clear(); }
@@ -1358,6 +1394,14 @@ int igemm_pick_bn(int n_real, int epi) {
 // returns the number of K slices (1 = no split).  Mirrors dispatch()'s tile choice.
 int igemm_plan_splits(const IgemmParams& p, int dtype) {
   if (p.epi != EPI_STORE || p.rowstats) return 1;
+  if (p.up4) {                 // 256-row tiles: K slices until every CU has a work item, at least 10 K tiles per slice
+    const long t256 = (long)(p.M / 256) * (p.N / 160);
+    const int nk0 = 4 * (p.C0 + p.C1) / 64;
+    int sp = t256 >= 240 ? 1 : (int)((num_cus() + t256 / 2) / t256);
+    if (sp > nk0 / 10) sp = nk0 / 10;
+    if (sp > 8) sp = 8;
+    return sp < 2 ? 1 : sp;
+  }
   if (p.C2 == 0 && g_big == kDefaultPolicy && g_force_cfg < 0 && igemm_ws_ok(p, dtype)) return igemm_ws_splits(p);
   if (const TunedEntry* e = tuned_lookup(p, dtype)) return e->splits;
   const int bke = dtype == DT_BF16 ? 64 : 32;
@@ -1387,6 +1431,45 @@ size_t igemm_partial_bytes(const IgemmParams& p) {
   return p.splits > 1 ? (size_t)p.splits * p.M * p.N * sizeof(float) : 0;
 }
 
+int g_up4_mode = 1;
+void igemm_set_up4_mode(int on) { g_up4_mode = on ? 1 : 0; }
+int igemm_get_up4_mode() { return g_up4_mode; }
+bool igemm_up4_ok(int B, int H, int W, int C, int N, int dtype) {
+  return g_up4_mode && dtype == DT_BF16 && C % 64 == 0 && N % 160 == 0 && ((long)B * H * W) % 256 == 0 && g_big == kDefaultPolicy && g_force_cfg < 0;
+}
+namespace {
+// OIHW fp32 3x3 -> [phase = 2 py + px][Npad][tap = 2 a + b][Cipad]: the taps of the 3x3 window that fall on the same source pixel of
+// the low-resolution map, summed in fp32.  Row group a of phase py: py = 0 -> {ky 0}, {ky 1, 2}; py = 1 -> {ky 0, 1}, {ky 2}.
+template <typename T>
+__global__ void pack_up4_kernel(const float* __restrict__ w, T* __restrict__ out, int Co, int Ci, int Npad, int Cipad) {
+  const size_t total = (size_t)4 * Npad * 4 * Cipad;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Cipad);
+    size_t r = i / Cipad;
+    const int tap = (int)(r & 3);
+    r >>= 2;
+    const int n = (int)(r % Npad), ph = (int)(r / Npad);
+    float acc = 0.f;
+    if (n < Co && c < Ci) {
+      const int py = ph >> 1, px = ph & 1, a = tap >> 1, b = tap & 1;
+      const int ky0 = py == 0 ? (a == 0 ? 0 : 1) : (a == 0 ? 0 : 2), ky1 = py == 0 ? (a == 0 ? 0 : 2) : (a == 0 ? 1 : 2);
+      const int kx0 = px == 0 ? (b == 0 ? 0 : 1) : (b == 0 ? 0 : 2), kx1 = px == 0 ? (b == 0 ? 0 : 2) : (b == 0 ? 1 : 2);
+      const float* wp = w + ((size_t)n * Ci + c) * 9;
+      for (int ky = ky0; ky <= ky1; ++ky)
+        for (int kx = kx0; kx <= kx1; ++kx) acc += wp[ky * 3 + kx];
+    }
+    out[i] = from_f32<T>(acc);
+  }
+}
+}  // namespace
+int launch_pack_up4(const float* w, void* out, int Co, int Ci, int Npad, int Cipad, int dtype, hipStream_t s) {
+  const size_t total = (size_t)16 * Npad * Cipad;
+  const size_t blocks = (total + 255) / 256;
+  const unsigned g = (unsigned)(blocks < 16384 ? blocks : 16384);
+  if (dtype == DT_BF16) hipLaunchKernelGGL(pack_up4_kernel<bf16_t>, dim3(g), dim3(256), 0, s, w, (bf16_t*)out, Co, Ci, Npad, Cipad);
+  else hipLaunchKernelGGL(pack_up4_kernel<float>, dim3(g), dim3(256), 0, s, w, (float*)out, Co, Ci, Npad, Cipad);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
 void igemm_set_xt_mode(int on) { g_xt_mode = on ? 1 : 0; }
 int igemm_get_xt_mode() { return g_xt_mode; }
 bool igemm_xt_ok(const IgemmParams& p, int dtype) {
@@ -1459,7 +1542,11 @@ int launch_igemm(const IgemmParams& p, int dtype, hipStream_t s) {
   const int bke = dtype == DT_BF16 ? 64 : 32;
   if (p.M <= 0 || p.N <= 0 || p.N % 32 != 0) return -2;
   if (p.C0 % bke != 0 || p.C1 % bke != 0 || (p.C0 + p.C1) == 0) return -2;
-  if (p.taps != 1 && p.taps != 9) return -2;
+  if (p.up4) {
+    if (dtype != DT_BF16 || p.taps != 4 || p.stride != 1 || p.up || p.cm || p.C2 || p.epi != EPI_STORE || p.rowstats || p.resid || p.rowbias ||
+        p.N % 160 != 0 || p.M % 1024 != 0 || p.M != 4 * p.B * p.Ho * p.Wo || p.Hi != p.Ho || p.Wi != p.Wo)
+      return -2;
+  } else if (p.taps != 1 && p.taps != 9) return -2;
   if (p.cm && (p.taps != 9 || p.stride != 1 || p.up || (p.pad >= 0 && p.pad != 1))) return -2;
   if (p.n_valid % 4 != 0 && p.epi != EPI_NCHW_F32) return -2;
   if (p.epi == EPI_GEGLU && p.N % 128 != 0) return -2;

@@ -57,6 +57,12 @@ struct IgemmParams {
                     // (diffusers Downsample2D(padding=0) of the AutoencoderKL encoder); the bottom/right edge is bounds-checked
   int stride = 1;   // 1 | 2
   int up = 0;       // nearest x2 upsample folded into the gather (Upsample2D)
+  // up4 (round 5): conv3x3(nearest_x2(x)) as four 2x2-tap phase convs on the LOW-resolution map.  An output pixel (2i + py, 2j + px)
+  // of the upsampled map only ever sees 2 x 2 distinct source pixels - rows {i-1, i} (py = 0) or {i, i+1} (py = 1), columns
+  // likewise - so the nine taps collapse into four with pre-summed weights: K = 4 C instead of 9 C, 2.25 x fewer MACs, same
+  // result up to the rounding of the summed weights.  The launch walks 4 * B * Hi * Wi virtual rows ordered (phase, image, i, j);
+  // taps = 4, Hi = Ho, Wi = Wo = the low-resolution map, W = [4 phases][N][4 taps][C], out = [B, 2Hi * 2Wi, ldo].
+  int up4 = 0;
   int cm = 0;       // 3x3 only: W is packed in channel-major K order, k = (channel tile, tap, channel in tile), instead of
                     // (tap, channel); needs stride 1, pad 1, no upsample (launch_igemm checks)
   int M = 0;        // B*Ho*Wo
@@ -86,7 +92,7 @@ struct IgemmParams {
   int no_finish = 0;             // splits > 1: leave the slabs as they are, the caller runs its own finish (launch_finish_groupnorm)
   const void* zeros = nullptr;   // >= 16 B of zeros (set by the launcher)
   // set by the launcher: divisions the kernels need (by Ho*Wo, Wo, the number of n tiles / tiles / K slices, K tiles per tap)
-  FastDiv fd_hwo, fd_wo, fd_nt, fd_ntiles, fd_nsplit, fd_tpt;
+  FastDiv fd_hwo, fd_wo, fd_nt, fd_ntiles, fd_nsplit, fd_tpt, fd_mphase;
   int x3 = 0;                    // fp32 launches only: split-bf16 arithmetic (hi + lo, three bf16 MFMAs per product block) instead of
                                  // the exact fp32 MFMA - compute_dtype "bf16x3" of the handles
   int dbg = 0;                   // ablation flags for profiling experiments (results are wrong when != 0)
@@ -109,6 +115,12 @@ void ops_bench_knob(int key, int value);   // ldmseg_bench_igemm (ops_api.hip): 
 void igemm_set_cm_mode(int mode);
 int igemm_get_cm_mode();
 bool igemm_conv_cm(int hw, int ctot, int n, int k, int stride, int up, int dtype);
+// conv3x3 on a nearest-x2 upsampled map as four 2x2 phase convs (IgemmParams::up4): whether the layer shape / map size has the
+// launch and debug key 21 allows it, and the weight packing it reads ([4][Npad][4][Cipad] from OIHW fp32)
+bool igemm_up4_ok(int B, int H, int W, int C, int N, int dtype);
+void igemm_set_up4_mode(int on);
+int igemm_get_up4_mode();
+int launch_pack_up4(const float* w, void* out, int Co, int Ci, int Npad, int Cipad, int dtype, hipStream_t s);
 bool igemm_xt_ok(const IgemmParams& p, int dtype);   // the launch (with src2 / C2 set) has an extra-tap instantiation and key 19 allows it
 void igemm_set_xt_mode(int on);
 int igemm_get_xt_mode();
@@ -122,7 +134,7 @@ void igemm_force_cfg(int cfg);   // tuning tool: >= 0 runs every launch with tha
 int igemm_get_dbg();       // current (policy << 8) | ablation flags
 int igemm_default_dbg();   // the shipped value
 // template instantiation + plan of the most recent launch_igemm (test introspection)
-struct IgemmDispatch { int dtype, bm, bn, wm, wn, nst, pipe, ldr, splits, grid, lnf, cm, ws, xt; };   // ws: waves of igemm_ws_kernel (0: igemm_kernel)
+struct IgemmDispatch { int dtype, bm, bn, wm, wn, nst, pipe, ldr, splits, grid, lnf, cm, ws, xt, up4; };   // ws: waves of igemm_ws_kernel (0: igemm_kernel)
 IgemmDispatch igemm_last_dispatch();
 std::string igemm_dispatch_name(const IgemmDispatch& d);
 void igemm_log_enable(int on);      // start (and clear) / stop recording the distinct instantiations launched

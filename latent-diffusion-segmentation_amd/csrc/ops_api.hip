@@ -398,8 +398,14 @@ static int op_igemm_impl(const float* x, const float* x2, const float* w, const 
   p.rowbias = rowbias; p.rb_stride = Co;
   p.resid = rp; p.ldr = cout; p.out = op; p.ldo = cout; p.epi = epi; p.silu = silu;
   p.x3 = x3;
+  if (up && k == 3 && stride == 1 && !Ci2 && !geglu && !resid && !rowbias && !silu && igemm_up4_ok(B, H, W, c0, Np, dtype) && Ci == c0) {
+    // the engine's form of an upsampler conv: four 2x2 phase convs on the low-resolution map (IgemmParams::up4)
+    void* w4 = t.get((size_t)16 * Np * c0 * es(dtype));
+    if (launch_pack_up4(w, w4, Co, Ci, Np, c0, dtype, s)) return -3;
+    p.W = w4; p.taps = 4; p.up = 0; p.up4 = 1; p.Ho = H; p.Wo = W; p.M = 4 * B * H * W; p.cm = 0;
+  }
   const size_t wbytes_ = (size_t)Np * k * k * ct * es(dtype);
-  if (dtype == DT_BF16 && !geglu && !cm && Np % 256 == 0 && (k * k * ct) % 64 == 0) {     // the fragment-major packing igemm_ws.hip streams
+  if (dtype == DT_BF16 && !geglu && !cm && !p.up4 && Np % 256 == 0 && (k * k * ct) % 64 == 0) {     // the fragment-major packing igemm_ws.hip streams
     void* wf = t.get(wbytes_);
     if (launch_pack_ws(wp, wf, Np, k * k * ct, s)) return -3;
     p.Wf = wf;
@@ -419,13 +425,14 @@ static int op_igemm_impl(const float* x, const float* x2, const float* w, const 
   if (r) return r;
   if (time_iters > 0 && us_per_launch) {        // kernel timing (tools/): launches back to back on the stream, HIP events around
     // the weights of a layer are cold in the real forward (1.6 GB of them stream through per step): rotate over copies
-    const size_t wbytes = (size_t)Np * k * k * ct * es(dtype);
+    const size_t wbytes = p.up4 ? (size_t)16 * Np * c0 * es(dtype) : (size_t)Np * k * k * ct * es(dtype);
+    const void* wsrc = p.W;                       // (the up4 launch reads its own packing)
     int rot = g_bench_rot < 1 ? 1 : g_bench_rot;
-    std::vector<const void*> wc(1, wp), wfc(1, p.Wf);
+    std::vector<const void*> wc(1, wsrc), wfc(1, p.Wf);
     for (int i = 1; i < rot; ++i) {
       void* c = t.get(wbytes);
       if (!c) break;
-      (void)hipMemcpyAsync(c, wp, wbytes, hipMemcpyDeviceToDevice, s);
+      (void)hipMemcpyAsync(c, wsrc, wbytes, hipMemcpyDeviceToDevice, s);
       const void* cf = nullptr;
       if (p.Wf) {
         void* q = t.get(wbytes);

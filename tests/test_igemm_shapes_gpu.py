@@ -29,7 +29,8 @@ def L():
     from ldmseg_amd import _lib
     assert _lib.lib().ldmseg_debug_get(1) == _lib.lib().ldmseg_debug_get(-1), "a previous test leaked a tile policy"
     assert _lib.lib().ldmseg_debug_get(12) == 3 and _lib.lib().ldmseg_debug_get(14) == 3, "a previous test leaked a fused-kernel switch"
-    assert _lib.lib().ldmseg_debug_get(19) == 1 and _lib.lib().ldmseg_debug_get(17) == 0 and _lib.lib().ldmseg_debug_get(20) == 1, \
+    assert _lib.lib().ldmseg_debug_get(19) == 1 and _lib.lib().ldmseg_debug_get(17) == 0 and _lib.lib().ldmseg_debug_get(20) == 1 and \
+        _lib.lib().ldmseg_debug_get(21) == 1, \
         "a previous test leaked a GEMM-path switch"
     return _lib
 

@@ -1164,3 +1164,37 @@ def test_resnet_tail_extra_tap(L, case):
                                               P(out), 0, None, None) == -4
     finally:
         lib.ldmseg_debug_set(19, 1)
+
+
+# ---- upsampler conv as four 2x2 phase convs on the low-resolution map (igemm.hip UP4, round 5) ----
+@pytest.mark.parametrize("case", [(8, 320, 8, 320), (2, 640, 16, 640), (4, 64, 8, 160), (1, 128, 16, 320), (16, 1280, 8, 1280)])
+def test_upsampler_conv_as_phase_convs(L, case):
+    """F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, b, padding=1) - diffusers' Upsample2D - as the engine runs it in
+    bf16: 4 B H W virtual rows (phase, image, i, j), K = 4 C with the 3x3 taps that fall on one source pixel summed beforehand.
+    Reference on the bf16-rounded INPUT and the fp32 weights rounded per tap (the kernel rounds the per-phase sums instead: the
+    bound allows for that), plus an exact check of the weight sums against a torch restatement; debug key 21 = 0 gives the nine-tap
+    launch on the same operands."""
+    B, Ci, H, Co = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Ci, H, H, generator=g)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) / (9 * Ci) ** 0.5
+    b = torch.randn(Co, generator=g)
+    ref = F.conv2d(F.interpolate(bf16_round(x), scale_factor=2.0, mode="nearest"), w, b, padding=1)       # unrounded weights
+    out = torch.empty(ref.shape, device="cuda")
+    dx, dw, db = dev(x), dev(w), dev(b)
+    lib = L.lib()
+    assert lib.ldmseg_op_igemm(P(dx), None, P(dw), P(db), None, None, B, Ci, 0, H, H, Co, 3, 1, 1, 0, 0, 0, BF16, P(out), None) == 0
+    torch.cuda.synchronize()
+    name = L.igemm_last_kernel()
+    assert ",up4" in name, name
+    assert rel_err(out, ref) < 8e-3, (case, name)
+    try:
+        lib.ldmseg_debug_set(21, 0)
+        out9 = torch.empty(ref.shape, device="cuda")
+        assert lib.ldmseg_op_igemm(P(dx), None, P(dw), P(db), None, None, B, Ci, 0, H, H, Co, 3, 1, 1, 0, 0, 0, BF16, P(out9), None) == 0
+        torch.cuda.synchronize()
+        assert ",up4" not in L.igemm_last_kernel()
+    finally:
+        lib.ldmseg_debug_set(21, 1)
+    assert rel_err(out9, ref) < 8e-3
+    assert float((out - out9).norm() / out9.norm()) < 6e-3          # two roundings of the same convolution

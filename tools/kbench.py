@@ -95,6 +95,8 @@ if __name__ == "__main__":
             L.ldmseg_debug_set(7, 1)
         if os.environ.get("CFG"):
             L.ldmseg_debug_set(5, int(os.environ["CFG"]))
+        if os.environ.get("UP4"):            # upsampler convs as four 2x2 phase convs (debug key 21)
+            L.ldmseg_debug_set(21, int(os.environ["UP4"]))
         if os.environ.get("WS"):             # weight-streaming kernel: mode | (max M / 4) << 8 | (min K tiles) << 20
             L.ldmseg_debug_set(17, int(os.environ["WS"], 0))
         igemm(SHAPES[int(sys.argv[2])], dt, iters=int(os.environ.get("ITERS", 20)))

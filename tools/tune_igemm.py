@@ -50,6 +50,8 @@ for case in SHAPES:
     H = H0 * LAT // 64
     if Ci < 64:
         continue                      # conv_in: K is one padded tile, nothing to choose
+    if os.environ.get("ONLY") and not eval(os.environ["ONLY"], {"case": case, "Ci": Ci, "Ci2": Ci2, "Co": Co, "k": k, "H0": H0, "use_res": use_res}):
+        continue                      # e.g. ONLY="k == 1 and Ci2 and use_res" (round 5: the chained ff.net.2 + proj_out shapes)
     ct = Ci + Ci2
     ln = k == 1 and not Ci2 and not use_res and (geglu or Co == 3 * Ci)      # norm1 -> q|k|v, norm3 -> GEGLU run folded
     x = torch.randn(B, Ci, H, H, device="cuda")
