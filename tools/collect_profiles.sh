@@ -32,8 +32,14 @@ python tools/ab_forward.py "12=0,14=0,16=0,2=7" "12=3,14=0,16=0,2=7" "12=3,14=1,
 # round 5: same-box A/B against the round-4 kernels (scratch/lib_r04.so = the library at the first round-5 commit: round-4 kernels + ABI additions)
 [ -f scratch/lib_r04.so ] && { LDMSEG_HIP_LIB=scratch/lib_r04.so python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras --no-images --no-torch-reference --profile-steps 0 > $O/bench_r04_lib_same_box.json 2>/dev/null; python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras --no-images --no-torch-reference --profile-steps 0 > $O/bench_this_lib_same_box.json 2>/dev/null; }
 # round 5: the weight-streaming kernel (opt-in) against igemm_kernel on the small-map shapes, cold weights; the parity-grade modes
-( for i in 45 46 48 52 31 34 35 39; do for ws in 0 0x20001 0x20005 0x20003; do ROT=1 WS=$ws python tools/kbench.py igemm1 $i 2>&1 | grep "M=" | sed "s/^/ws=$ws /"; done; done ) > $O/kbench_ws.txt 2>&1
+( for i in 45 46 48 52 31 34 35 39; do for ws in 0 0x20001 0x20005 0x20003; do ROT=1 WS=$ws python tools/kbench.py igemm1 $i 2>&1 | grep "M=" | sed "s/^/ws=$ws /"; done; done ) > $O/kbench_ws.txt 2>/dev/null
 python tools/fam.py bf16x3 fp32 bf16 2>&1 | grep -v amdgpu.ids > $O/modes_ms_per_forward.txt
+# round 5: the three data-flow restructurings switched on one by one in one process (19: conv2 + conv_shortcut in one launch, 20: ff.net.2 +
+# proj_out chained, 21: upsampler convs as four 2x2 phase convs), and the resnet-tail / upsampler launches against what they replace
+python tools/ab_forward.py "19=0,20=0,21=0" "19=1,20=0,21=0" "19=1,20=1,21=0" "19=1,20=1,21=1" --rounds 3 2>&1 | grep -v amdgpu.ids > $O/ab_round5_knobs.txt
+python tools/xt_bench.py 2>&1 | grep -v amdgpu.ids > $O/xt_bench.txt
+python tools/acc_round5.py 2>&1 | grep -v amdgpu.ids > $O/accuracy_round5.txt
+( for i in 12 29 44; do for v in 0 1; do UP4=$v python tools/kbench.py igemm1 $i 2>/dev/null | grep "M=" | sed "s/^/up4=$v /"; done; done ) > $O/kbench_up4.txt
 [ -f scratch/lib_stamp.so ] && { export LDMSEG_OP_TIMING_NHWC=1; for shape in "320 64 320" "640 32 640" "1280 16 1280" "320 64 320 1" "640 32 640 1"; do LDMSEG_HIP_LIB=scratch/lib_stamp.so python tools/stamps2.py $shape 2>&1 | grep -v amdgpu.ids; done > $O/igemm_stamps.txt; unset LDMSEG_OP_TIMING_NHWC; }
 [ -f scratch/lib_r03.so ] && false && { LDMSEG_HIP_LIB=scratch/lib_r03.so python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras --no-images --no-torch-reference --profile-steps 0 > $O/bench_r03_lib_same_box.json 2>/dev/null; }
 python tools/kbench.py gn > $O/kbench_groupnorm.txt 2>&1
