@@ -130,8 +130,15 @@ def test_real_coco_pairs_host_side(golden):
         assert np.array_equal(bits, g[f"bits_{k}"].astype(np.float32)) and np.array_equal(ign, g[f"ignore_{k}"])
         assert np.array_equal(o_bits.decode_bitmap(2 * bits - 1), g[f"decoded_{k}"]) and np.array_equal(g[f"decoded_{k}"], remapped)
         r_img = np.asarray(crop_resize(img, (512, 512), "bicubic"))
-        assert np.array_equal(r_img[::8, ::8], g[f"resized_sample_{k}"])
-        assert hashlib.sha256(r_img.tobytes()).digest() == g[f"resized_sha_{k}"].tobytes()
+        # JPEG decoding (libjpeg-turbo) and PIL's bicubic filter are allowed to differ by a rounding step between library versions
+        # (ADVICE r04): the subsampled pixels are compared with a tolerance everywhere, bit for bit (and through the sha of the whole
+        # image) only under the Pillow version the fixture was generated with
+        import PIL
+        diff = np.abs(r_img[::8, ::8].astype(np.int16) - g[f"resized_sample_{k}"].astype(np.int16))
+        assert diff.max() <= 2 and (diff > 0).mean() < 0.02, (PIL.__version__, int(diff.max()))
+        if PIL.__version__ == "12.2.0":
+            assert np.array_equal(r_img[::8, ::8], g[f"resized_sample_{k}"])
+            assert hashlib.sha256(r_img.tobytes()).digest() == g[f"resized_sha_{k}"].tobytes()
         r_ids = np.asarray(crop_resize(Image.fromarray(remapped), (512, 512), "nearest"))
         assert np.array_equal(r_ids, g[f"resized_ids_{k}"])
     assert sizes == [(480, 640), (640, 427)]                      # (width, height): one portrait, one landscape
