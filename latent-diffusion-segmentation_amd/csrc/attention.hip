@@ -38,15 +38,24 @@ template <typename T, int D> struct AttnCfg {
 
 // row statistics reduce over the 4 lanes (l, l^16, l^32, l^48) that share a query row with
 // v_permlane16_swap / v_permlane32_swap (common.h) instead of LDS round trips (ds_bpermute)
-template <typename T, int D, int QF>
-__global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qkv, T* __restrict__ out,
+// X3 (compute_dtype "bf16x3", round 5): T = bf16 inside, fp32 in HBM.  q, k, v are split into bf16 hi + lo (lo = bf16(x - hi)) - K and V
+// once per tile when they are committed to the LDS, as two planes of the bf16 layout; Q once per workgroup; the probabilities in
+// registers - and every product block is three MFMAs, Xl.Yh + Xh.Yl + Xh.Yh, with fp32 accumulation: the arithmetic of igemm.hip's
+// x3 path on the bf16 kernel's structure (8 keys per 16-byte chunk, ones row of V^T for the row sums).
+template <typename T, int D, int QF, bool X3 = false>
+__global__ __launch_bounds__(256) void attention_kernel(const std::conditional_t<X3, float, T>* __restrict__ qkv,
+                                                        std::conditional_t<X3, float, T>* __restrict__ out,
                                                         int N, int C, int heads, float scale_log2e) {
+  using IO = std::conditional_t<X3, float, T>;
+  static_assert(!X3 || sizeof(T) == 2, "the split-bf16 form runs on the bf16 layout");
   using Cfg = AttnCfg<T, D>;
   constexpr int PC = Chunk<T>::N;
   constexpr int NCH = BKV * Cfg::DCH;          // real 16-B chunks of one K (or V) tile
   constexpr int KIT = (NCH + 255) / 256;       // chunks per thread per tile
+  constexpr int KR_N = X3 ? 2 * KIT : KIT;     // X3: a chunk of 8 elements is two 16-byte fp32 loads
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int STAGE = Cfg::KS_BYTES + Cfg::VT_BYTES;
+  constexpr int PLANE = Cfg::KS_BYTES + Cfg::VT_BYTES;
+  constexpr int STAGE = X3 ? 2 * PLANE : PLANE;   // X3: the lo plane sits PLANE bytes behind the hi plane
   constexpr int NST = (2 * STAGE <= 144 * 1024) ? 2 : 1;   // two stages (one barrier per key tile) when they fit
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -64,10 +73,21 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
   const int bh = wg / nqb;
   const int h = bh % heads, b = bh / heads;
   const size_t ld = (size_t)3 * C;
-  const T* qbase = qkv + (size_t)b * N * ld + (size_t)h * D;
+  const IO* qbase = qkv + (size_t)b * N * ld + (size_t)h * D;
   const unsigned char* kbase = (const unsigned char*)(qbase + C);
   const unsigned char* vbase = (const unsigned char*)(qbase + 2 * C);
-  const size_t ldb = ld * sizeof(T);
+  const size_t ldb = ld * sizeof(IO);
+  // hi / lo split of eight floats (two 16-byte chunks) into two bf16 chunks
+  auto split8 = [&](const u32x4& c0, const u32x4& c1, u32x4& hi, u32x4& lo) __attribute__((always_inline)) {
+    const unsigned w0[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float f0 = bits_f32(w0[2 * i]), f1 = bits_f32(w0[2 * i + 1]);
+      const unsigned hh = pack_bf16x2(f0, f1);
+      hi[i] = hh;
+      lo[i] = pack_bf16x2(f0 - bits_f32(hh << 16), f1 - bits_f32(hh & 0xffff0000u));
+    }
+  };
 
   // K/V tile staging: global -> registers (issued before the MFMA block of the previous tile, so
   // the L2/HBM latency hides under it) -> LDS after that tile's last LDS read.
@@ -77,7 +97,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
   // Two register sets (A, B) so that two K/V tiles can be in flight.  The bodies are macros over
   // the set name: passing the arrays by reference into lambdas made hipcc index them dynamically
   // (-> scratch memory, 6x slower).
-  u32x4 kregA[KIT], vregA[KIT], kregB[KIT], vregB[KIT];
+  u32x4 kregA[KR_N], vregA[KR_N], kregB[KR_N], vregB[KR_N];
 #define ATTN_PREFETCH(T_, KR, VR)                                                                          \
   {                                                                                                        \
     const int kv0_ = (T_) * BKV;                                                                           \
@@ -87,9 +107,16 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
         /* rows past N are clamped to the last key: their scores are masked to -inf below, so the */      \
         /* (finite) duplicate K/V data never contributes */                                                \
         const int krow = i / Cfg::DCH, kch = i - krow * Cfg::DCH;                                          \
-        KR[it] = *(const u32x4*)(kbase + (size_t)min(kv0_ + krow, N - 1) * ldb + kch * 16);                \
         const int vrow = i & (BKV - 1), vch = i / BKV;                                                     \
-        VR[it] = *(const u32x4*)(vbase + (size_t)min(kv0_ + vrow, N - 1) * ldb + vch * 16);                \
+        if constexpr (X3) {                                                                                \
+          const unsigned char* kp_ = kbase + (size_t)min(kv0_ + krow, N - 1) * ldb + kch * 32;             \
+          const unsigned char* vp_ = vbase + (size_t)min(kv0_ + vrow, N - 1) * ldb + vch * 32;             \
+          KR[2 * it] = *(const u32x4*)kp_; KR[2 * it + 1] = *(const u32x4*)(kp_ + 16);                     \
+          VR[2 * it] = *(const u32x4*)vp_; VR[2 * it + 1] = *(const u32x4*)(vp_ + 16);                     \
+        } else {                                                                                           \
+          KR[it] = *(const u32x4*)(kbase + (size_t)min(kv0_ + krow, N - 1) * ldb + kch * 16);              \
+          VR[it] = *(const u32x4*)(vbase + (size_t)min(kv0_ + vrow, N - 1) * ldb + vch * 16);              \
+        }                                                                                                  \
       }                                                                                                    \
     }                                                                                                      \
   }
@@ -101,11 +128,23 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
       const int i = tid + it * 256;                                                                        \
       if (it + 1 < KIT || i < NCH) {                                                                       \
         const int krow = i / Cfg::DCH, kch = i - krow * Cfg::DCH;                                          \
-        *(u32x4*)(Ks_ + krow * Cfg::KROW + kch * 16) = KR[it];                                             \
         const int vrow = i & (BKV - 1), vch = i / BKV;                                                     \
-        const u32x4 vv_ = VR[it];                                                                          \
-        _Pragma("unroll") for (int k = 0; k < PC; ++k)                                                     \
-            *(T*)(Vt_ + (vch * PC + k) * Cfg::VROW + vrow * sizeof(T)) = chunk_elem<T>(vv_, k);            \
+        if constexpr (X3) {                                                                                \
+          u32x4 kh_, kl_, vh_, vl_;                                                                        \
+          split8(KR[2 * it], KR[2 * it + 1], kh_, kl_);                                                    \
+          split8(VR[2 * it], VR[2 * it + 1], vh_, vl_);                                                    \
+          *(u32x4*)(Ks_ + krow * Cfg::KROW + kch * 16) = kh_;                                              \
+          *(u32x4*)(Ks_ + PLANE + krow * Cfg::KROW + kch * 16) = kl_;                                      \
+          _Pragma("unroll") for (int k = 0; k < PC; ++k) {                                                 \
+            *(T*)(Vt_ + (vch * PC + k) * Cfg::VROW + vrow * sizeof(T)) = chunk_elem<T>(vh_, k);            \
+            *(T*)(Vt_ + PLANE + (vch * PC + k) * Cfg::VROW + vrow * sizeof(T)) = chunk_elem<T>(vl_, k);    \
+          }                                                                                                \
+        } else {                                                                                           \
+          *(u32x4*)(Ks_ + krow * Cfg::KROW + kch * 16) = KR[it];                                           \
+          const u32x4 vv_ = VR[it];                                                                        \
+          _Pragma("unroll") for (int k = 0; k < PC; ++k)                                                   \
+              *(T*)(Vt_ + (vch * PC + k) * Cfg::VROW + vrow * sizeof(T)) = chunk_elem<T>(vv_, k);          \
+        }                                                                                                  \
       }                                                                                                    \
     }                                                                                                      \
   }
@@ -129,12 +168,31 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
   // Q fragments (MFMA B operand): lane (q = lq, g = lg) holds chunk kg*4+g of its row
   const int q0 = qb * 64 * QF + wave * 16 * QF;
   uint4 qf[QF][Cfg::KG];
+  uint4 ql[X3 ? QF : 1][X3 ? Cfg::KG : 1];       // X3: lo halves of Q
 #pragma unroll
   for (int a = 0; a < QF; ++a) {
     const int q = q0 + a * 16 + lq;
 #pragma unroll
     for (int kg = 0; kg < Cfg::KG; ++kg) {
       const int ch = kg * 4 + lg;
+      if constexpr (X3) {
+        u32x4 c0 = {0u, 0u, 0u, 0u}, c1 = c0;
+        if (q < N && ch < Cfg::DCH) {
+          const unsigned char* qp = (const unsigned char*)(qbase + (size_t)q * ld) + ch * 32;
+          c0 = *(const u32x4*)qp;
+          c1 = *(const u32x4*)(qp + 16);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {                     // d^-1/2 * log2(e) folded into Q before the split
+          c0[e] = f32_bits(bits_f32(c0[e]) * scale_log2e);
+          c1[e] = f32_bits(bits_f32(c1[e]) * scale_log2e);
+        }
+        u32x4 hh, ll;
+        split8(c0, c1, hh, ll);
+        qf[a][kg] = make_uint4(hh[0], hh[1], hh[2], hh[3]);
+        ql[a][kg] = make_uint4(ll[0], ll[1], ll[2], ll[3]);
+        continue;
+      }
       qf[a][kg] = (q < N && ch < Cfg::DCH) ? *(const uint4*)((const unsigned char*)(qbase + (size_t)q * ld) + ch * 16)
                                             : make_uint4(0, 0, 0, 0);
       // fold d^-1/2 * log2(e) into Q once, so that the scores come out of the MFMA in exp2 units
@@ -186,6 +244,13 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
 #pragma unroll
       for (int f = 0; f < 4; ++f) {
         const uint4 kf = *(const uint4*)(Ks + krow_f[f] * Cfg::KROW + (kg * 4 + lg) * 16);
+        if constexpr (X3) {                              // small terms first
+          const uint4 kfl = *(const uint4*)(Ks + PLANE + krow_f[f] * Cfg::KROW + (kg * 4 + lg) * 16);
+#pragma unroll
+          for (int a = 0; a < QF; ++a) mma_kgroup<T>(kfl, qf[a][kg], s[a][f]);
+#pragma unroll
+          for (int a = 0; a < QF; ++a) mma_kgroup<T>(kf, ql[a][kg], s[a][f]);
+        }
 #pragma unroll
         for (int a = 0; a < QF; ++a) mma_kgroup<T>(kf, qf[a][kg], s[a][f]);
       }
@@ -242,12 +307,20 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
 #pragma unroll
     for (int g = 0; g < Cfg::PG; ++g) {
       uint4 pb[QF];
+      uint4 pbl[X3 ? QF : 1];
 #pragma unroll
       for (int a = 0; a < QF; ++a) {
         if constexpr (sizeof(T) == 2) {
           const float p0 = s[a][2 * g][0], p1 = s[a][2 * g][1], p2 = s[a][2 * g][2], p3 = s[a][2 * g][3];
           const float p4 = s[a][2 * g + 1][0], p5 = s[a][2 * g + 1][1], p6 = s[a][2 * g + 1][2], p7 = s[a][2 * g + 1][3];
           pb[a] = make_uint4(pack_bf16x2(p0, p1), pack_bf16x2(p2, p3), pack_bf16x2(p4, p5), pack_bf16x2(p6, p7));
+          if constexpr (X3) {
+            const unsigned hx = pb[a].x, hy = pb[a].y, hz = pb[a].z, hw = pb[a].w;
+            pbl[a] = make_uint4(pack_bf16x2(p0 - bits_f32(hx << 16), p1 - bits_f32(hx & 0xffff0000u)),
+                                pack_bf16x2(p2 - bits_f32(hy << 16), p3 - bits_f32(hy & 0xffff0000u)),
+                                pack_bf16x2(p4 - bits_f32(hz << 16), p5 - bits_f32(hz & 0xffff0000u)),
+                                pack_bf16x2(p6 - bits_f32(hw << 16), p7 - bits_f32(hw & 0xffff0000u)));
+          }
         } else {
           const float p0 = s[a][g][0], p1 = s[a][g][1], p2 = s[a][g][2], p3 = s[a][g][3];
           pb[a] = make_uint4(f32_bits(p0), f32_bits(p1), f32_bits(p2), f32_bits(p3));
@@ -256,6 +329,13 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
 #pragma unroll
       for (int d = 0; d < Cfg::DF; ++d) {
         const uint4 vf = *(const uint4*)(Vt + (d * 16 + lq) * Cfg::VROW + (g * 4 + lg) * 16);
+        if constexpr (X3) {
+          const uint4 vfl = *(const uint4*)(Vt + PLANE + (d * 16 + lq) * Cfg::VROW + (g * 4 + lg) * 16);
+#pragma unroll
+          for (int a = 0; a < QF; ++a) mma_kgroup<T>(vfl, pb[a], o[a][d]);
+#pragma unroll
+          for (int a = 0; a < QF; ++a) mma_kgroup<T>(vf, pbl[a], o[a][d]);
+        }
 #pragma unroll
         for (int a = 0; a < QF; ++a) mma_kgroup<T>(vf, pb[a], o[a][d]);
       }
@@ -310,14 +390,14 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
     const float inv = 1.0f / l;
     const int q = q0 + a * 16 + lq;
     if (q >= N) continue;
-    T* op = out + ((size_t)b * N + q) * C + (size_t)h * D;
+    IO* op = out + ((size_t)b * N + q) * C + (size_t)h * D;
 #pragma unroll
     for (int d = 0; d < Cfg::DF; ++d) {
       const int dd = d * 16 + 4 * lg;
       if (dd >= D) continue;
       const f32x4 v = o[a][d] * inv;
       const float v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3];
-      if constexpr (sizeof(T) == 2) {
+      if constexpr (sizeof(IO) == 2) {
         *(uint2*)(op + dd) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
       } else {
         *(f32x4*)(op + dd) = v;
@@ -326,12 +406,13 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
   }
 }
 
-template <typename T, int D, int QF>
+template <typename T, int D, int QF, bool X3 = false>
 int run(const void* qkv, void* out, int B, int N, int C, int heads, hipStream_t s) {
   using Cfg = AttnCfg<T, D>;
-  const size_t stage = (size_t)(Cfg::KS_BYTES + Cfg::VT_BYTES);
+  using IO = std::conditional_t<X3, float, T>;
+  const size_t stage = (size_t)(Cfg::KS_BYTES + Cfg::VT_BYTES) * (X3 ? 2 : 1);
   const size_t lds = (2 * stage <= 144 * 1024 ? 2 : 1) * stage;
-  auto kern = attention_kernel<T, D, QF>;
+  auto kern = attention_kernel<T, D, QF, X3>;
   static bool attr_set[64] = {};     // per device: a process may hold handles on several GPUs
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
@@ -341,7 +422,7 @@ int run(const void* qkv, void* out, int B, int N, int C, int heads, hipStream_t 
   }
   const int nqb = (N + 64 * QF - 1) / (64 * QF);
   const float scale_log2e = (1.0f / sqrtf((float)D)) * 1.4426950408889634f;
-  hipLaunchKernelGGL(kern, dim3(nqb * heads * B), dim3(256), lds, s, (const T*)qkv, (T*)out, N, C, heads, scale_log2e);
+  hipLaunchKernelGGL(kern, dim3(nqb * heads * B), dim3(256), lds, s, (const IO*)qkv, (IO*)out, N, C, heads, scale_log2e);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
@@ -359,6 +440,18 @@ int dispatch(const void* qkv, void* out, int B, int N, int C, int heads, hipStre
   }
 }
 
+// fp32 tensors, split-bf16 products (compute_dtype "bf16x3")
+int dispatch_x3(const void* qkv, void* out, int B, int N, int C, int heads, hipStream_t s) {
+  const int d = C / heads;
+  const bool big = N >= 256;
+  switch (d) {
+    case 40: return big ? run<bf16_t, 40, 2, true>(qkv, out, B, N, C, heads, s) : run<bf16_t, 40, 1, true>(qkv, out, B, N, C, heads, s);
+    case 80: return big ? run<bf16_t, 80, 2, true>(qkv, out, B, N, C, heads, s) : run<bf16_t, 80, 1, true>(qkv, out, B, N, C, heads, s);
+    case 160: return run<bf16_t, 160, 1, true>(qkv, out, B, N, C, heads, s);
+    default: return -2;
+  }
+}
+
 }  // namespace
 
 void attention_set_qf1(int v) { g_attn_qf1 = v; }
@@ -367,6 +460,7 @@ int launch_attention3(const void* qkv, void* out, int B, int N, int C, int heads
 
 int launch_attention(const void* qkv, void* out, int B, int N, int C, int heads, int dtype, hipStream_t s) {
   if (C % heads != 0 || N <= 0) return -2;
+  if (dtype == 2) return dispatch_x3(qkv, out, B, N, C, heads, s);      // LDMSEG_BF16X3: fp32 in HBM, three bf16 MFMAs per product block
   // bf16 perf mode, head dims 40 / 80: the LDS-DMA + folded-max kernel of attention3.hip (knob value 2 forces this file's
   // kernel for A/B measurements; 1 = 16 query rows per wave)
   if (dtype == DT_BF16 && g_attn_qf1 != 2 && g_attn_qf1 != 3) {      // 0, 1, 4..7: variants of attention3.hip

@@ -848,7 +848,7 @@ int run_transformer(Exec& ex, const TransformerW& t, const Act& x, Act* out) {
       if (!ex.dry()) TRY(launch_attention_fp8(qkv.p, scratch, att.p, ex.B, N, C, 8, ex.s));
     } else if (!ex.dry()) {
       TRY(ex.ws_ok());
-      TRY(launch_attention(qkv.p, att.p, ex.B, N, C, 8, ex.dt, ex.s));
+      TRY(launch_attention(qkv.p, att.p, ex.B, N, C, 8, ex.x3 ? 2 : ex.dt, ex.s));   // 2 = fp32 tensors, split-bf16 products
     }
   }
   // h = to_out(att) + h  (in place on h)

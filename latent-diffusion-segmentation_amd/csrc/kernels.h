@@ -201,6 +201,7 @@ int launch_layernorm(const void* x, void* y, const float* gamma, const float* be
                      float eps, int silu, int dtype, hipStream_t s);
 
 // self-attention on fused qkv [B, N, 3C] (q | k | v, channel = head*d + i) -> out [B, N, C]
+// dtype 2 = fp32 tensors with the products as three bf16 MFMAs on hi/lo splits (compute_dtype "bf16x3")
 int launch_attention(const void* qkv, void* out, int B, int N, int C, int heads, int dtype, hipStream_t s);
 
 // Row-local fusion of the transformer feed-forward at the 320-channel level (tfuse.hip): LayerNorm_3 -> GEGLU -> ff.net.2 (+h)

@@ -1121,6 +1121,25 @@ def test_split_bf16_layernorm_folded_gemm(L, M, K, N, geglu):
     assert rel_err(out, y) < 2e-4, name
 
 
+@pytest.mark.parametrize("B,N,Cc", [(2, 4096, 320), (2, 1024, 640), (8, 256, 1280), (3, 64, 1280), (1, 200, 320), (1, 33, 640)])
+def test_split_bf16_attention(L, B, N, Cc):
+    """dtype 2 of ldmseg_op_attention: q, k, v and the probabilities split into bf16 hi + lo, every score / output block
+    as three bf16 MFMAs (attention.hip X3), tensors fp32 in HBM.  Against the fp64 reference on the UNROUNDED inputs, with a
+    dominant key that moves the running maximum; bound 1e-4 (the exact-fp32 kernel sits at 2e-5, bf16 at 2e-2)."""
+    g = torch.Generator().manual_seed(N + Cc + 2)
+    qkv = torch.randn(B, N, 3 * Cc, generator=g)
+    qkv[:, :, :Cc] *= 2.0
+    qkv[0, N // 2, Cc:Cc + 40] += 6.0
+    ref = attention_ref(qkv, B, N, Cc)
+    out = torch.empty(B, N, Cc, device="cuda")
+    dq = dev(qkv)
+    assert L.lib().ldmseg_op_attention(P(dq), B, N, Cc, 8, 2, P(out), None) == 0, L.lib().ldmseg_last_error()
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    e = rel_err(out, ref)
+    assert e < 1e-4, e
+
+
 # ---- resnet tail as one launch: conv2 + conv_shortcut through an extra centre tap (igemm.hip XT, round 5) ----
 # (B, H, W, C = cout, Cs, Cs2, splits)
 XT_CASES = {
