@@ -299,7 +299,9 @@ int ldmseg_profile_dump(const char* path);
  * with igemm_kernel); must be set BEFORE a handle is created (the handle then holds the fragment-major weight packing);
  * key 19 = resnet conv2 + conv_shortcut as one launch with an extra centre tap (bf16; default 1, 0 = two launches);
  * key 20 = ff.net.2 and proj_out of the 640- / 1280-channel transformers as one chained Linear over [g | h] (bf16; default 1);
- * key 21 = upsampler convs (nearest x2 -> conv3x3) as four 2x2-tap phase convs on the low-resolution map (bf16; default 1). */
+ * key 21 = upsampler convs (nearest x2 -> conv3x3) as four 2x2-tap phase convs on the low-resolution map (bf16; default 1);
+ * key 22 = the GroupNorm in front of a 320-channel transformer as a statistics pass + a sweep over the fused entry's LDS tile
+ * (tproj.hip; bf16, maps of a multiple of 128 pixels; default 1, 0 = a GroupNorm launch of its own, n > 1 = n <= 64 pixel chunks). */
 int ldmseg_debug_set(int key, int value);
 /* current value of a knob (keys 1, 9, 12, 14, 15, 16, 17, 19, 20, 21); key -1 = the shipped default of key 1.  Tests restore through this, never a literal.
  * key 10 = number of cooperative-GroupNorm workgroups that took the self-computing path in ldmseg_op_* launches so far. */

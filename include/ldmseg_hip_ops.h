@@ -55,6 +55,13 @@ int ldmseg_op_panoptic_from_decoder(const float* x4, int B, int C, int H4, int W
 int ldmseg_op_transformer_in(const float* x, const float* wp, const float* bp, const float* gamma, const float* beta, const float* wq,
                              const float* wk, const float* wv, int M, int C, float eps, int dtype, int mode, float* h_out, float* qkv_out,
                              int time_iters, float* us_per_call, void* stream);
+/* The same behind the transformer's GroupNorm (32 groups, eps gn_eps, no SiLU; diffusers Transformer2DModel.norm) over
+ * x = [images][M / images][C] rows.  gn_mode 0: a GroupNorm launch, then the entry as above; gn_mode 1 (mode 1 only, M / images a
+ * multiple of 128): the statistics pass alone, the normalisation applied to the row tile inside the fused kernel (tproj.hip). */
+int ldmseg_op_gn_transformer_in(const float* x, const float* gn_gamma, const float* gn_beta, float gn_eps, int images, int gn_mode,
+                                const float* wp, const float* bp, const float* gamma, const float* beta, const float* wq,
+                                const float* wk, const float* wv, int M, int C, float eps, int dtype, int mode, float* h_out,
+                                float* qkv_out, int time_iters, float* us_per_call, void* stream);
 
 /* One conv / GEMM layer launched exactly as the engine launches it inside a forward (NHWC operands, the engine's
  * split-K plan when splits == 0, row-major store epilogue with bias / per-image bias row / residual / SiLU, or GEGLU):

@@ -25,6 +25,8 @@ thread_local std::string g_err;
 // tile policy and forced instantiation decide the split-K slice counts, i.e. the size of the partial-sum scratch).
 // Handles remember the epoch their cached plan was made under and re-plan when it moved.
 int g_plan_epoch = 0;
+int g_gnfold_mode = 1;  // debug key 22: 1 (default) = the GroupNorm in front of a 320-channel transformer as a statistics pass + a sweep inside
+                        // proj_ln_qkv (tproj.hip); 0 = a GroupNorm launch of its own; n > 1 = on, with n pixel chunks per image
 int g_ffp_mode = 1;     // debug key 20: 1 (default) = ff.net.2 and proj_out of the 640- / 1280-channel transformers as one chained Linear
 int fail(int code, const std::string& msg) {
   g_err = msg;
@@ -448,6 +450,22 @@ struct Exec {
     return launch_groupnorm(g, dt, s);
   }
 
+  // GroupNorm statistics only ({mean, M2} per image, pixel chunk and group): the consumer (tproj.hip) combines and applies them
+  int groupnorm_stats(const NormW& n, const Act& x, float eps, GnFold* gf) {
+    if (x.C != n.C) return fail(LDMSEG_E_SHAPE, "groupnorm: channel mismatch");
+    GNParams g;
+    g.src0 = x.p; g.C0 = x.C;
+    g.B = B; g.HW = x.H * x.W; g.groups = 32;
+    g.nchunk = g_gnfold_mode > 1 ? (g_gnfold_mode > 64 ? 64 : g_gnfold_mode) : proj_qkv_gn_chunks(B, g.HW);
+    g.partial = (float*)ws->scratch((size_t)B * g.nchunk * 32 * 2 * sizeof(float));
+    gf->partial = g.partial; gf->gamma = n.g; gf->beta = n.b; gf->nchunk = g.nchunk; gf->HW = g.HW; gf->eps = eps;
+    const double bytes = 1.0 * B * g.HW * x.C * esize(dt);
+    ProfScope ps(2, s, 0, bytes, dry(), "stats HW=" + std::to_string(g.HW) + " C=" + std::to_string(x.C));
+    if (dry()) return 0;
+    TRY(ws_ok());
+    return launch_groupnorm_stats(g, dt, s);
+  }
+
   // LayerNorm statistics only (the normalisation itself is folded into the consuming GEMM)
   int rowstats(const Act& x, float eps, float* stats) {
     const int M = B * x.H * x.W;
@@ -806,8 +824,12 @@ int run_transformer(Exec& ex, const TransformerW& t, const Act& x, Act* out) {
   const size_t m = ws->mark();
   const int C = t.C, N = x.H * x.W, M = ex.B * N;
   Act n, h, qkv, att, ff;
-  TRY(ex.groupnorm(t.norm, x, nullptr, 1e-6f, 0, &n));
-  if (t.in_stream && proj_qkv_fused_ok(C, M, ex.dt)) {
+  const bool entry_fused = t.in_stream && proj_qkv_fused_ok(C, M, ex.dt);
+  const bool gn_fold = entry_fused && g_gnfold_mode && proj_qkv_gn_fold_ok(N);
+  GnFold gf;
+  if (gn_fold) TRY(ex.groupnorm_stats(t.norm, x, 1e-6f, &gf));     // the norm's apply pass runs inside the fused entry, on its LDS tile
+  else TRY(ex.groupnorm(t.norm, x, nullptr, 1e-6f, 0, &n));
+  if (entry_fused) {
     // 320-channel level: proj_in -> norm1 -> q|k|v in one row-local launch (tproj.hip): h is written once and not read back
     h = ex.new_act(C, x.H, x.W, false);
     qkv = ex.new_act(3 * C, x.H, x.W, false);
@@ -816,7 +838,8 @@ int run_transformer(Exec& ex, const TransformerW& t, const Act& x, Act* out) {
     ProfScope ps(0, ex.s, flops, bytes, ex.dry(), "M=" + std::to_string(M) + " proj_ln_qkv C=" + std::to_string(C));
     if (!ex.dry()) {
       TRY(ex.ws_ok());
-      const int r = launch_proj_qkv_fused(n.p, h.p, qkv.p, t.in_stream, t.in_bias, igemm_zero_page(), M, C, 1e-5f, ex.s);
+      const int r = launch_proj_qkv_fused(gn_fold ? x.p : n.p, h.p, qkv.p, t.in_stream, t.in_bias, igemm_zero_page(), M, C, 1e-5f,
+                                          gn_fold ? &gf : nullptr, ex.s);
       if (r) return fail(r == -2 ? LDMSEG_E_SHAPE : LDMSEG_E_HIP, "launch_proj_qkv_fused failed");
     }
   } else {
@@ -1922,6 +1945,7 @@ int ldmseg_debug_set(int key, int value) {
   if (key == 17) { igemm_ws_set_mode(value & 7, (value >> 8) & 0xfff ? ((value >> 8) & 0xfff) * 4 : 0, (value >> 20) & 0xff); ++g_plan_epoch; return 0; }
   if (key == 19) { igemm_set_xt_mode(value); ++g_plan_epoch; return 0; }   // 1 (default): resnet conv2 + conv_shortcut as one launch (bf16)
   if (key == 20) { g_ffp_mode = value ? 1 : 0; ++g_plan_epoch; return 0; }
+  if (key == 22) { g_gnfold_mode = value < 0 ? 0 : value; ++g_plan_epoch; return 0; }   // GroupNorm folded into the fused transformer entry: 0 off, 1 on, n > 1 on with n pixel chunks
   if (key == 21) { igemm_set_up4_mode(value); ++g_plan_epoch; return 0; }   // 1 (default): upsampler convs as four 2x2 phase convs (bf16)
   if (key == 6 || key == 7) { ops_bench_knob(key, value); return 0; }   // ldmseg_bench_igemm: 6 = weight copies rotated, 7 = folded-LN launch
   static unsigned long long ts_ptr = 0;                // keys 3/4: low/high half of a device stamp buffer (ablate builds)
@@ -1941,6 +1965,7 @@ int ldmseg_debug_get(int key) {
   if (key == 17) return igemm_ws_get_mode();
   if (key == 19) return igemm_get_xt_mode();
   if (key == 20) return g_ffp_mode;
+  if (key == 22) return g_gnfold_mode;
   if (key == 21) return igemm_get_up4_mode();
   if (key == 10) { const long long n = gn_coop_fallbacks(nullptr); return n > 0x7fffffffll ? 0x7fffffff : (int)n; }   // ring regions (ldmseg_op_* launches)
   return 0;

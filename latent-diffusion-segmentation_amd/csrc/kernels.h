@@ -188,6 +188,9 @@ long long gn_coop_fallbacks(const void* region);
 const void* gn_sync_diag_ptr(const void* region);      // device address of a region's 8-byte fallback counter
 int gn_nchunk(int B, int HW);
 int launch_groupnorm(const GNParams& p, int dtype, hipStream_t s);
+// statistics only: p.partial[b][chunk][group] = {mean, M2} of p.nchunk pixel chunks of ceil(HW / nchunk) pixels (gn_partial_kernel);
+// out / gamma / beta / silu are not used.  Consumer: launch_proj_qkv_fused with a GnFold (tproj.hip)
+int launch_groupnorm_stats(const GNParams& p, int dtype, hipStream_t s);
 // Split-K finish of a conv fused with the GroupNorm (+SiLU) that consumes it (resnet conv1 -> norm2 on the 8x8 / 16x16
 // maps): out = GN(sum_z partial[z] + bias + rowbias[image]) in ONE launch; the conv's own output is never stored.
 // ip: the igemm launch (partial, splits, M, N, n_valid, bias, rowbias, rb_stride); g: B, HW, C0 = channels, gamma, beta,
@@ -220,8 +223,19 @@ void proj_qkv_set_mode(int m);
 int proj_qkv_get_mode();
 size_t proj_qkv_stream_bytes(int C);
 int launch_pack_proj_qkv_stream(const void* wp, const void* wqkv, void* out, int C, hipStream_t s);
+// gn != null: x is the transformer's RAW input and its GroupNorm (32 groups, no SiLU) runs inside the kernel from the statistics of
+// launch_groupnorm_stats (partial [B][nchunk][32][2]); M % HW == 0, HW % 128 == 0 (proj_qkv_gn_fold_ok)
+struct GnFold {
+  const float* partial = nullptr;
+  const float* gamma = nullptr;
+  const float* beta = nullptr;
+  int nchunk = 0, HW = 0;
+  float eps = 1e-6f;
+};
+bool proj_qkv_gn_fold_ok(int HW);
+int proj_qkv_gn_chunks(int B, int HW);    // nchunk for launch_groupnorm_stats (<= 64: the kernel keeps a lane's records in registers)
 int launch_proj_qkv_fused(const void* x, void* h, void* qkv, const void* stream, const float* bias4, const void* zeros, int M, int C, float eps,
-                          hipStream_t s);
+                          const GnFold* gn, hipStream_t s);
 int launch_mlp_fused(const void* h, void* out, const void* x2, const void* stream, const float* bias1, const float* bias2,
                      const float* bias3, const void* zeros, int M, int C, float eps, int proj, int rows_per_image, hipStream_t s);
 void mlp_fused_set_dbg(int flags);          // bit 8: no start-chunk rotation; bits 0-7: phase ablation (LDMSEG_TFUSE_ABLATE builds only)

@@ -1541,6 +1541,32 @@ bool finish_groupnorm_ok(int B, int HW, int C, int dtype) {
   if (g_gn_variant & 8) return false;       // tuning bit 3: keep finish and norm apart
   return dtype == DT_BF16 ? finish_gn_plan<bf16_t>(B, HW, C, &a, &b, &c, &d) : finish_gn_plan<float>(B, HW, C, &a, &b, &c, &d);
 }
+// Statistics half of the two-launch path on its own (round 5): partial[b][chunk][group] = {mean, M2} over `per` = ceil(HW / nchunk)
+// pixels per chunk, nothing else is written.  The consumer (tproj.hip: the transformer's norm folded into the fused entry) combines
+// the chunks and applies the affine to its own rows.
+template <typename T>
+int run_gn_stats(const GNParams& pin, hipStream_t s) {
+  constexpr int PC = Chunk<T>::N;
+  GNParams p = pin;
+  const int C = p.C0 + p.C1;
+  if (p.groups < 1 || C % p.groups != 0 || C % PC != 0 || p.C0 % PC != 0 || p.groups > 32 || !p.partial) return -2;
+  p.cpg = C / p.groups;
+  p.fd_cpg = fastdiv_make(p.cpg);
+  if (p.cpg < PC && 2 * p.cpg != PC) return -2;
+  if (C / PC > 256 * kMaxIter) return -2;
+  const int nvec = C / PC;
+  p.vx = nvec < 256 ? nvec : 256;
+  p.ty = 256 / p.vx;
+  p.fd_vx = fastdiv_make(p.vx);
+  if (p.nchunk < 1 || p.nchunk > 128) return -2;
+  p.per = (p.HW + p.nchunk - 1) / p.nchunk;
+  hipLaunchKernelGGL(gn_partial_kernel<T>, dim3(p.nchunk, p.B), dim3(256), 0, s, p);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+int launch_groupnorm_stats(const GNParams& p, int dtype, hipStream_t s) {
+  return dtype == DT_BF16 ? run_gn_stats<bf16_t>(p, s) : run_gn_stats<float>(p, s);
+}
+
 int launch_finish_groupnorm(const IgemmParams& ip, const GNParams& g, int dtype, hipStream_t s) {
   return dtype == DT_BF16 ? run_finish_gn<bf16_t>(ip, g, s) : run_finish_gn<float>(ip, g, s);
 }

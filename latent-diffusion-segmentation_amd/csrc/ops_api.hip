@@ -718,12 +718,31 @@ int ldmseg_op_transformer_ff(const float* h, const float* x, const float* gamma,
 // The entry of a transformer on caller-supplied weights: h = x Wp^T + bp (proj_in as a Linear on [M][C] rows), q|k|v = [Wq | Wk | Wv]
 // LayerNorm(h; gamma, beta).  mode 0: the unfused launches (GEMM, row statistics, folded-LayerNorm GEMM); 1: the row-local fused
 // kernel (tproj.hip; bf16, C = 320, M % 128 == 0).  Outputs fp32 h [M][C], qkv [M][3C].  time_iters > 0 also times the path.
-int ldmseg_op_transformer_in(const float* x, const float* wp, const float* bp, const float* gamma, const float* beta, const float* wq,
-                             const float* wk, const float* wv, int M, int C, float eps, int dtype, int mode, float* h_out, float* qkv_out,
-                             int time_iters, float* us_per_call, void* stream) {
+static int transformer_in_impl(const float* x, const float* gn_gamma, const float* gn_beta, float gn_eps, int gn_images, int gn_mode,
+                               const float* wp, const float* bp, const float* gamma, const float* beta, const float* wq,
+                               const float* wk, const float* wv, int M, int C, float eps, int dtype, int mode, float* h_out, float* qkv_out,
+                               int time_iters, float* us_per_call, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   Temp t;
   if (C % bke(dtype) || (mode != 0 && (dtype != DT_BF16 || !proj_qkv_stream_bytes(C) || M % 128))) return -2;
+  // GroupNorm in front (gn_gamma != null; x = [gn_images][HW][C] rows): gn_mode 0 = a launch of its own, 1 = statistics pass + the
+  // sweep inside the fused kernel (mode 1 only)
+  GNParams gp;
+  GnFold gf;
+  void* xn = nullptr;
+  if (gn_gamma) {
+    if (gn_images < 1 || M % gn_images || C % 32 || (gn_mode == 1 && (mode != 1 || !proj_qkv_gn_fold_ok(M / gn_images)))) return -2;
+    xn = t.get((size_t)M * C * es(dtype));
+    float* gg = (float*)t.get(C * sizeof(float));
+    float* gb = (float*)t.get(C * sizeof(float));
+    (void)hipMemcpyAsync(gg, gn_gamma, C * sizeof(float), hipMemcpyDeviceToDevice, s);
+    (void)hipMemcpyAsync(gb, gn_beta, C * sizeof(float), hipMemcpyDeviceToDevice, s);
+    gp.C0 = C; gp.B = gn_images; gp.HW = M / gn_images; gp.groups = 32; gp.gamma = gg; gp.beta = gb; gp.eps = gn_eps; gp.silu = 0;
+    gp.out = xn;
+    gp.nchunk = gn_mode == 1 ? proj_qkv_gn_chunks(gp.B, gp.HW) : gn_nchunk(gp.B, gp.HW);
+    gp.partial = (float*)t.get((size_t)gp.B * gp.nchunk * 32 * 2 * sizeof(float));
+    gf.partial = gp.partial; gf.gamma = gg; gf.beta = gb; gf.nchunk = gp.nchunk; gf.HW = gp.HW; gf.eps = gn_eps;
+  }
   void* xp = t.get((size_t)M * C * es(dtype));
   void* hp = t.get((size_t)M * C * es(dtype));
   void* qp = t.get((size_t)M * 3 * C * es(dtype));
@@ -763,12 +782,22 @@ int ldmseg_op_transformer_in(const float* x, const float* wp, const float* bp, c
     return launch_igemm(p, dtype, s);
   };
   auto run = [&]() -> int {
+    const void* xin = xp;
+    if (gn_gamma) {
+      gp.src0 = xp;
+      if (gn_mode == 1) {
+        if (int r = launch_groupnorm_stats(gp, dtype, s)) return r;
+        return launch_proj_qkv_fused(xp, hp, qp, stream_w, bias4, igemm_zero_page(), M, C, eps, &gf, s);
+      }
+      if (int r = launch_groupnorm(gp, dtype, s)) return r;
+      xin = xn;
+    }
     if (mode == 0) {
-      if (int r = gemm(xp, wpp, C, bias4, hp, nullptr, nullptr)) return r;
+      if (int r = gemm(xin, wpp, C, bias4, hp, nullptr, nullptr)) return r;
       if (int r = launch_rowstats(hp, stats, M, C, eps, dtype, s)) return r;
       return gemm(hp, wqkv, 3 * C, bias4 + C, qp, stats, c1);
     }
-    return launch_proj_qkv_fused(xp, hp, qp, stream_w, bias4, igemm_zero_page(), M, C, eps, s);
+    return launch_proj_qkv_fused(xin, hp, qp, stream_w, bias4, igemm_zero_page(), M, C, eps, nullptr, s);
   };
   if (int r = run()) return r;
   if (time_iters > 0 && us_per_call) {
@@ -787,6 +816,22 @@ int ldmseg_op_transformer_in(const float* x, const float* wp, const float* bp, c
   from_dev_dtype(hp, h_out, (size_t)M * C, dtype, s);
   from_dev_dtype(qp, qkv_out, (size_t)M * 3 * C, dtype, s);
   return 0;
+}
+int ldmseg_op_transformer_in(const float* x, const float* wp, const float* bp, const float* gamma, const float* beta, const float* wq,
+                             const float* wk, const float* wv, int M, int C, float eps, int dtype, int mode, float* h_out, float* qkv_out,
+                             int time_iters, float* us_per_call, void* stream) {
+  return transformer_in_impl(x, nullptr, nullptr, 0.f, 0, 0, wp, bp, gamma, beta, wq, wk, wv, M, C, eps, dtype, mode, h_out, qkv_out,
+                             time_iters, us_per_call, stream);
+}
+// The same behind the transformer's GroupNorm (32 groups, no SiLU) over x = [images][M / images][C] rows: gn_mode 0 = a GroupNorm
+// launch, then the entry as above; gn_mode 1 (mode 1 only) = statistics pass + the apply sweep inside the fused kernel (tproj.hip).
+int ldmseg_op_gn_transformer_in(const float* x, const float* gn_gamma, const float* gn_beta, float gn_eps, int images, int gn_mode,
+                                const float* wp, const float* bp, const float* gamma, const float* beta, const float* wq,
+                                const float* wk, const float* wv, int M, int C, float eps, int dtype, int mode, float* h_out,
+                                float* qkv_out, int time_iters, float* us_per_call, void* stream) {
+  if (!gn_gamma || !gn_beta) return -2;
+  return transformer_in_impl(x, gn_gamma, gn_beta, gn_eps, images, gn_mode, wp, bp, gamma, beta, wq, wk, wv, M, C, eps, dtype, mode, h_out,
+                             qkv_out, time_iters, us_per_call, stream);
 }
 
 // The step tail kernel (tail.hip, bf16): eps = conv2d(x, w, bias, padding=1) with 320 -> 4 channels on [B,320,H,W] and, when

@@ -84,7 +84,16 @@ struct ProjQkvParams {
   int M;
   float eps;
   int rot, stagger;
+  // GroupNorm fold (round 5): x is the RAW transformer input; gn_partial = launch_groupnorm_stats' {mean, M2} per (image, pixel chunk,
+  // group), combined per wave and applied to the tile in the LDS before pass 0.  Null: x is already normalised.
+  const float* gn_partial;
+  const float* gn_gamma;
+  const float* gn_beta;
+  int gn_nchunk, gn_per, gn_hw;
+  float gn_eps;
 };
+constexpr int kCPG = kC / 32;             // channels per GroupNorm group
+constexpr int kGnMaxChunks = 64;          // pixel chunks per image the in-kernel combination takes (32 records per lane, held in registers)
 
 __global__ __launch_bounds__(768, 3) void proj_ln_qkv_kernel(const ProjQkvParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -138,6 +147,7 @@ __global__ __launch_bounds__(768, 3) void proj_ln_qkv_kernel(const ProjQkvParams
     int land = 10;                          // this wave's ring pieces through the unit that must have landed next
     wait_pieces(iss - land);                // the row tile (issued first) and unit 0 have landed
     __syncthreads();                        // A
+    if (p.gn_partial) asm volatile("s_barrier" ::: "memory");        // A2: pairs with the barrier behind the GroupNorm sweep
     for (int t = 0; t < nunits; ++t) {
       if (t == kUnitsPerPass) {             // pairs with the two barriers around the in-place LayerNorm after pass 0
         asm volatile("s_barrier" ::: "memory");
@@ -168,7 +178,79 @@ __global__ __launch_bounds__(768, 3) void proj_ln_qkv_kernel(const ProjQkvParams
   f32x4 bnext[5];
 #pragma unroll
   for (int a = 0; a < 5; ++a) bnext[a] = *(const f32x4*)(p.bias + wn * 80 + a * 16 + lg * 4);
+  // ---- GroupNorm fold, part 1 (in the shadow of the tile's DMA): every wave combines the image's per-chunk {mean, M2} itself - lane l
+  // takes every second chunk of group l >> 1, the pair is summed in a fixed order (closed form of Chan's update against the first
+  // chunk's mean, as norm.hip's gn_reduce_stats) - and every thread turns the statistics of ITS 8 channels (one 16-byte chunk of
+  // the tile, at most two groups) into y = x * ga + gb.  There is no LDS left for a table: the exchange is ds_bpermute.
+  float ga[8], gb[8];
+  const int gn_j = tid % 40, gn_rg = tid / 40;          // chunk of 8 channels, row group (12 of them; threads 480.. idle)
+  if (p.gn_partial) {
+    const int img = m0 / p.gn_hw;                       // (a tile never straddles images: HW % 128 == 0, launch_proj_qkv_fused checks)
+    const int g = lane >> 1, half = lane & 1;
+    const float2* src = (const float2*)p.gn_partial + (size_t)img * p.gn_nchunk * 32 + g;
+    // all of the lane's chunk records are requested at once (one round trip to the L2; a rolled loop of dependent trips cost more than
+    // the GroupNorm launch this replaces)
+    float2 e[kGnMaxChunks / 2];
+    float cnt[kGnMaxChunks / 2];
+#pragma unroll
+    for (int i = 0; i < kGnMaxChunks / 2; ++i) {
+      const int ch = half + 2 * i;
+      const int p0 = ch * p.gn_per, np = min(p.gn_hw, p0 + p.gn_per) - p0;
+      const bool ok = ch < p.gn_nchunk && np > 0;
+      e[i] = src[(size_t)(ok ? ch : 0) * 32];
+      cnt[i] = ok ? (float)(np * kCPG) : 0.f;
+    }
+    const float K = __shfl(e[0].x, lane & ~1);          // chunk 0 of the group (always populated)
+    float n = 0.f, sd = 0.f;
+#pragma unroll
+    for (int i = 0; i < kGnMaxChunks / 2; ++i) { n += cnt[i]; sd += cnt[i] * (e[i].x - K); }
+    auto pair_sum = [&](float v) __attribute__((always_inline)) {
+      const float w = __shfl_xor(v, 1);
+      return half ? w + v : v + w;                      // same operand order on both partners
+    };
+    n = pair_sum(n);
+    sd = pair_sum(sd);
+    const float dbar = n > 0.f ? sd / n : 0.f;
+    float m2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < kGnMaxChunks / 2; ++i) {
+      const float d = (e[i].x - K) - dbar;
+      m2 += cnt[i] > 0.f ? e[i].y + cnt[i] * d * d : 0.f;
+    }
+    m2 = pair_sum(m2);
+    const float g_mean = K + dbar;
+    const float g_rstd = 1.0f / sqrtf((n > 0.f ? m2 / n : 0.f) + p.gn_eps);
+    const int c0 = gn_j * 8;
+    const int g0 = c0 / kCPG, g1 = min(g0 + 1, 31);
+    const int split = min(8, (g0 + 1) * kCPG - c0);     // channels [0, split) of the chunk belong to g0, the rest to g0 + 1
+    const float m_lo = __shfl(g_mean, 2 * g0), r_lo = __shfl(g_rstd, 2 * g0);
+    const float m_hi = __shfl(g_mean, 2 * g1), r_hi = __shfl(g_rstd, 2 * g1);
+    const f32x4 gm0 = *(const f32x4*)(p.gn_gamma + c0), gm1 = *(const f32x4*)(p.gn_gamma + c0 + 4);
+    const f32x4 bt0 = *(const f32x4*)(p.gn_beta + c0), bt1 = *(const f32x4*)(p.gn_beta + c0 + 4);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float gam = e < 4 ? gm0[e & 3] : gm1[e & 3], bet = e < 4 ? bt0[e & 3] : bt1[e & 3];
+      ga[e] = (e < split ? r_lo : r_hi) * gam;
+      gb[e] = bet - (e < split ? m_lo : m_hi) * ga[e];
+    }
+  }
   lds_barrier();                          // A: the row tile and unit 0 have landed
+  if (p.gn_partial) {
+    // ---- part 2: the affine on the tile in place (the arithmetic of gn_apply_kernel: one fused multiply-add per element, bf16 result)
+    if (gn_rg < 12) {
+      unsigned char* colp = XT + (gn_j >> 3) * (kBM * 128);
+#pragma unroll 2
+      for (int row = gn_rg; row < kBM; row += 12) {
+        unsigned char* q = colp + row * 128 + (((gn_j & 7) ^ (row & 7)) << 4);
+        float f[8];
+        Chunk<bf16_t>::unpack(*(const uint4*)q, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = f[e] * ga[e] + gb[e];
+        *(uint4*)q = Chunk<bf16_t>::pack(f);
+      }
+    }
+    lds_barrier();                        // A2: the normalised tile is visible
+  }
 
 #pragma unroll 1
   for (int pass = 0; pass < kNPass; ++pass) {
@@ -326,6 +408,15 @@ int g_tproj_mode = 3;     // bit 0: on; bit 1: loader block rotation
 }  // namespace
 
 bool proj_qkv_fused_ok(int C, int M, int dtype) { return (g_tproj_mode & 1) && C == kC && dtype == DT_BF16 && M > 0 && M % kBM == 0; }
+// the GroupNorm in front of the transformer as a statistics pass + a sweep inside the kernel: whole tiles of one image (32 groups of 10)
+bool proj_qkv_gn_fold_ok(int HW) { return HW > 0 && HW % kBM == 0; }
+int proj_qkv_gn_chunks(int B, int HW) {    // pixel chunks per image for launch_groupnorm_stats: <= 64, about two workgroups per CU in total
+  int n = 512 / (B > 0 ? B : 1);
+  if (n > kGnMaxChunks) n = kGnMaxChunks;
+  if (n < 4) n = 4;
+  while (n > 1 && HW / n < 32) n >>= 1;
+  return n;
+}
 void proj_qkv_set_mode(int m) { g_tproj_mode = m & 0xff; }
 int proj_qkv_get_mode() { return g_tproj_mode; }
 size_t proj_qkv_stream_bytes(int C) { return C == kC ? (size_t)kStreamBytes : 0; }
@@ -339,11 +430,17 @@ int launch_pack_proj_qkv_stream(const void* wp, const void* wqkv, void* out, int
 
 // x [M][320] bf16 -> h [M][320], qkv [M][960].  bias4: [4][320] fp32 (proj_in bias | W_q beta | W_k beta | W_v beta)
 int launch_proj_qkv_fused(const void* x, void* h, void* qkv, const void* stream, const float* bias4, const void* zeros, int M, int C, float eps,
-                          hipStream_t s) {
+                          const GnFold* gn, hipStream_t s) {
   if (C != kC || M < 1 || M % kBM || !x || !h || !qkv || !stream || !bias4 || !zeros) return -2;
   ProjQkvParams p;
   p.x = (const bf16_t*)x; p.h = (bf16_t*)h; p.qkv = (bf16_t*)qkv; p.stream = (const unsigned char*)stream; p.bias = bias4; p.zeros = zeros;
   p.M = M; p.eps = eps; p.rot = (g_tproj_mode >> 1) & 3; p.stagger = (g_tproj_mode >> 4) & 15;
+  p.gn_partial = nullptr; p.gn_gamma = p.gn_beta = nullptr; p.gn_nchunk = p.gn_per = p.gn_hw = 0; p.gn_eps = 0.f;
+  if (gn) {
+    if (!gn->partial || !gn->gamma || !gn->beta || !proj_qkv_gn_fold_ok(gn->HW) || M % gn->HW || gn->nchunk < 1 || gn->nchunk > kGnMaxChunks) return -2;
+    p.gn_partial = gn->partial; p.gn_gamma = gn->gamma; p.gn_beta = gn->beta;
+    p.gn_nchunk = gn->nchunk; p.gn_per = (gn->HW + gn->nchunk - 1) / gn->nchunk; p.gn_hw = gn->HW; p.gn_eps = gn->eps;
+  }
   static bool attr_set[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
@@ -351,7 +448,7 @@ int launch_proj_qkv_fused(const void* x, void* h, void* qkv, const void* stream,
     (void)hipFuncSetAttribute((const void*)proj_ln_qkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLds);
     attr_set[dev] = true;
   }
-  igemm_log_note("proj_ln_qkv<bf16>");
+  igemm_log_note(gn ? "proj_ln_qkv<bf16,gn>" : "proj_ln_qkv<bf16>");
   hipLaunchKernelGGL(proj_ln_qkv_kernel, dim3(M / kBM), dim3(768), kLds, s, p);
   return hipGetLastError() == hipSuccess ? 0 : -3;
 }

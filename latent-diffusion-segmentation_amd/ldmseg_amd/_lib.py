@@ -96,6 +96,7 @@ SIGNATURES = {
                                      _vp, _f, _f, _vp, _vp]),
     "ldmseg_op_transformer_ff": (_i, [_vp] * 10 + [_i, _i, _f, _i, _i, _vp, _i, C.POINTER(C.c_float), _vp]),
     "ldmseg_op_transformer_in": (_i, [_vp] * 8 + [_i, _i, _f, _i, _i, _vp, _vp, _i, C.POINTER(C.c_float), _vp]),
+    "ldmseg_op_gn_transformer_in": (_i, [_vp] * 3 + [_f, _i, _i] + [_vp] * 7 + [_i, _i, _f, _i, _i, _vp, _vp, _i, C.POINTER(C.c_float), _vp]),
     "ldmseg_bench_igemm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
                                 C.POINTER(C.c_float), _vp]),
     "ldmseg_bench_attention": (_i, [_vp, _i, _i, _i, _i, _i, _i, C.POINTER(C.c_float), _vp]),

@@ -30,7 +30,7 @@ def L():
     assert _lib.lib().ldmseg_debug_get(1) == _lib.lib().ldmseg_debug_get(-1), "a previous test leaked a tile policy"
     assert _lib.lib().ldmseg_debug_get(12) == 3 and _lib.lib().ldmseg_debug_get(14) == 3, "a previous test leaked a fused-kernel switch"
     assert _lib.lib().ldmseg_debug_get(19) == 1 and _lib.lib().ldmseg_debug_get(17) == 0 and _lib.lib().ldmseg_debug_get(20) == 1 and \
-        _lib.lib().ldmseg_debug_get(21) == 1, \
+        _lib.lib().ldmseg_debug_get(21) == 1 and _lib.lib().ldmseg_debug_get(22) == 1, \
         "a previous test leaked a GEMM-path switch"
     return _lib
 
@@ -287,6 +287,28 @@ def test_fused_transformer_entry_at_config_shape(L, cfg):
     l2 = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
     assert torch.isfinite(qkv).all() and l2(h, href) < 3e-3 and l2(qkv, qref) < 6e-3, (cfg, l2(h, href), l2(qkv, qref))
     SEEN[(cfg, BF16)].add("proj_ln_qkv<bf16>")
+
+
+@pytest.mark.parametrize("cfg", CONFIGS, ids=CFG_IDS)
+def test_fused_transformer_entry_with_groupnorm_at_config_shape(L, cfg):
+    """The same kernel with the transformer's GroupNorm folded in (statistics pass + apply sweep on the LDS tile: what the bf16
+    forward launches since round 5), at this configuration's image count and map size, against torch GroupNorm -> proj_in ->
+    LayerNorm_1 -> q|k|v on the bf16-rounded operands."""
+    import torch.nn.functional as F
+    from test_ops_gpu import _gtin_run, _tin_case, _tin_ref, bf16_round
+    B, lat = cfg
+    HW, M = lat * lat, B * lat * lat
+    g = torch.Generator().manual_seed(13 + M)
+    case = _tin_case(M, 320, 17 + M)
+    x = torch.randn(B, HW, 320, generator=g) * (0.5 + torch.rand(1, 1, 320, generator=g)) + 2.0 * torch.randn(1, 1, 320, generator=g)
+    gg = 1 + 0.3 * torch.randn(320, generator=g)
+    gb = 0.3 * torch.randn(320, generator=g)
+    xn = F.group_norm(bf16_round(x).permute(0, 2, 1).reshape(B, 320, HW, 1), 32, gg, gb, 1e-6).reshape(B, 320, HW).permute(0, 2, 1)
+    href, qref = _tin_ref(xn.reshape(M, 320), *case[1:])
+    h, qkv, _ = _gtin_run(L, x.reshape(M, 320), gg, gb, B, 1, case, M, 320, 1)
+    l2 = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    assert torch.isfinite(qkv).all() and l2(h, href) < 4e-3 and l2(qkv, qref) < 7e-3, (cfg, l2(h, href), l2(qkv, qref))
+    SEEN[(cfg, BF16)].add("proj_ln_qkv<bf16,gn>")
 
 
 @pytest.mark.parametrize("mode,dt", [("bf16", BF16), ("fp32", F32)])

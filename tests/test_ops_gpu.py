@@ -911,6 +911,62 @@ def test_transformer_in_fused_vs_torch_and_unfused(L, M):
     assert torch.equal(again[0], outs[1][0]) and torch.equal(again[1], outs[1][1])      # deterministic
 
 
+def _gtin_run(L, x, gg, gb, images, gn_mode, case, M, Cc, mode, iters=0):
+    h = torch.empty(M, Cc, device="cuda")
+    qkv = torch.empty(M, 3 * Cc, device="cuda")
+    keep = [dev(t) for t in (x, gg, gb)] + [dev(t) for t in case[1:]]
+    us = C.c_float(0)
+    r = L.lib().ldmseg_op_gn_transformer_in(P(keep[0]), P(keep[1]), P(keep[2]), 1e-6, images, gn_mode, *[P(t) for t in keep[3:]],
+                                            M, Cc, 1e-5, BF16, mode, P(h), P(qkv), iters, C.byref(us), None)
+    assert r == 0, (r, L.lib().ldmseg_last_error())
+    torch.cuda.synchronize()
+    return h.cpu(), qkv.cpu(), us.value
+
+
+@pytest.mark.parametrize("images,HW", [(1, 128), (3, 256), (2, 1024), (8, 4096), (1, 16384)])
+def test_transformer_in_with_groupnorm_folded(L, images, HW):
+    """The transformer's GroupNorm as a statistics pass + a sweep over the fused entry's LDS tile (round 5, tproj.hip `gn`):
+    against the same kernel behind a GroupNorm launch (same fused multiply-add on the same bf16 input, statistics combined
+    in another order: bf16-rounding-level agreement) and against torch on the bf16-rounded operands.  Channel means of
+    +-3 and per-image offsets make the statistics matter; 1 x 128 is a single tile, 8 x 4096 the configs[1] size,
+    1 x 16384 the 128 x 128 map of configs[4]."""
+    Cc, M = 320, images * HW
+    g = torch.Generator().manual_seed(7 * images + HW)
+    case = _tin_case(M, Cc, 3000 + M)
+    x = torch.randn(images, HW, Cc, generator=g) * (0.5 + torch.rand(1, 1, Cc, generator=g)) + 3.0 * torch.randn(1, 1, Cc, generator=g)
+    x = x + torch.randn(images, 1, 1, generator=g)
+    gg = 1 + 0.3 * torch.randn(Cc, generator=g)
+    gb = 0.3 * torch.randn(Cc, generator=g)
+    xb = bf16_round(x)
+    xn = F.group_norm(xb.permute(0, 2, 1).reshape(images, Cc, HW, 1), 32, gg, gb, 1e-6).reshape(images, Cc, HW).permute(0, 2, 1)
+    href, qref = _tin_ref(xn.reshape(M, Cc), *case[1:])
+    l2 = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    sep = _gtin_run(L, x.reshape(M, Cc), gg, gb, images, 0, case, M, Cc, 1)
+    fold = _gtin_run(L, x.reshape(M, Cc), gg, gb, images, 1, case, M, Cc, 1)
+    for nm, (h, qkv, _) in (("sep", sep), ("fold", fold)):
+        assert torch.isfinite(h).all() and torch.isfinite(qkv).all(), nm
+        assert l2(h, href) < 4e-3 and l2(qkv, qref) < 7e-3, (nm, l2(h, href), l2(qkv, qref))
+    assert l2(fold[0], sep[0]) < 2e-3 and l2(fold[1], sep[1]) < 4e-3, (l2(fold[0], sep[0]), l2(fold[1], sep[1]))
+    again = _gtin_run(L, x.reshape(M, Cc), gg, gb, images, 1, case, M, Cc, 1)
+    assert torch.equal(again[0], fold[0]) and torch.equal(again[1], fold[1])      # deterministic
+
+
+def test_transformer_in_groupnorm_fold_rejects_partial_tiles(L):
+    """A map whose pixel count is not a multiple of the 128-row tile keeps its GroupNorm launch (the engine asks proj_qkv_gn_fold_ok)."""
+    case = _tin_case(384, 320, 5)
+    x = torch.randn(384, 320)
+    keep = [dev(t) for t in (x, torch.ones(320), torch.zeros(320))] + [dev(t) for t in case[1:]]
+    h = torch.empty(384, 320, device="cuda")
+    qkv = torch.empty(384, 960, device="cuda")
+    us = C.c_float(0)
+    call = lambda images, gn_mode: L.lib().ldmseg_op_gn_transformer_in(
+        P(keep[0]), P(keep[1]), P(keep[2]), 1e-6, images, gn_mode, *[P(t) for t in keep[3:]], 384, 320, 1e-5, BF16, 1, P(h), P(qkv), 0,
+        C.byref(us), None)
+    assert call(2, 1) != 0          # 192 pixels per image
+    assert call(2, 0) == 0
+    assert call(3, 1) == 0          # 128 pixels per image
+
+
 def test_transformer_in_fused_rejects_what_it_does_not_cover(L):
     """Ragged row counts, other channel counts and fp32 are not the fused kernel's: the operator says so (the engine routes
     such shapes to the unfused launches)."""

@@ -414,18 +414,19 @@ def test_unet_fused_and_unfused_launch_sets_agree(unets):
     from ldmseg_amd import _lib
     lib = _lib.lib()
     shipped = {12: lib.ldmseg_debug_get(12), 14: lib.ldmseg_debug_get(14), 16: lib.ldmseg_debug_get(16), 2: 0, 19: lib.ldmseg_debug_get(19),
-               20: lib.ldmseg_debug_get(20), 21: lib.ldmseg_debug_get(21)}
+               20: lib.ldmseg_debug_get(20), 21: lib.ldmseg_debug_get(21), 22: lib.ldmseg_debug_get(22)}
     # (round 5: 19 = conv2 + conv_shortcut in one launch, 20 = ff.net.2 + proj_out as one chained Linear, 21 = upsampler convs as four
-    # 2x2 phase convs)
+    # 2x2 phase convs, 22 = the 320-channel transformers' GroupNorm as a statistics pass + a sweep inside the fused entry)
     assert shipped[12] == 3 and shipped[14] == 3 and shipped[16] == 3 and shipped[19] == 1 and shipped[20] == 1 and shipped[21] == 1
+    assert shipped[22] == 1
     x = torch.randn(2, 12, 64, 64, generator=torch.Generator().manual_seed(12)).to(DEV)
     ref16 = unets["bf16"](x, 500).sample.clone()
     ref32 = unets["fp32"](x, 500).sample.clone()
     l2 = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
     base = l2(ref16, ref32)
-    old = {12: 0, 14: 0, 16: 0, 2: 7, 19: 0, 20: 0, 21: 0}
+    old = {12: 0, 14: 0, 16: 0, 2: 7, 19: 0, 20: 0, 21: 0, 22: 0}
     try:
-        for keys in ([12], [14], [16], [2], [19], [20], [21], [12, 14, 16, 2, 19, 20, 21]):
+        for keys in ([12], [14], [16], [2], [19], [20], [21], [22], [12, 14, 16, 2, 19, 20, 21, 22]):
             for k in keys:
                 assert lib.ldmseg_debug_set(k, old[k]) == 0
             y16 = unets["bf16"](x, 500).sample.clone()
