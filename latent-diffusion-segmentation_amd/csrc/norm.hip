@@ -139,40 +139,53 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const GNParams p) {
       const int g0 = fd_div(c0, p.fd_cpg);
       split = min(PC, (g0 + 1) * cpg - c0);  // elements [0,split) -> g0, rest -> g0+1
       int pix = p0 + ty;
-      if (pix < p1) {
-        float f[PC];
-        Chunk<T>::unpack(load_cat<T>(p, b, pix, v), f);
-        k0 = f[0];
-#pragma unroll
-        for (int e = 1; e < PC; ++e) if (e == split) k1 = f[e];
-      }
-      // four pixels per trip: the loads are issued together, so each thread keeps 64 B in flight
-      for (; pix + 3 * TY < p1; pix += 4 * TY) {
-        uint4 raw[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) raw[u] = load_cat<T>(p, b, pix + u * TY, v);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          float f[PC];
-          Chunk<T>::unpack(raw[u], f);
-#pragma unroll
-          for (int e = 0; e < PC; ++e) {
-            if (e < split) { const float d = f[e] - k0; s0 += d; q0 += d * d; }
-            else { const float d = f[e] - k1; s1 += d; q1 += d * d; }
-          }
-        }
-        npix += 4;
-      }
-      for (; pix < p1; pix += TY) {
-        const uint4 raw = load_cat<T>(p, b, pix, v);
+      // Every trip requests all of its pixels before the first use (eight, then four, then the last one to three together): a thread's
+      // ~11 pixels of a 64-pixel chunk are two round trips to the L2.  (Round 5: the earlier form - one load for the shift, trips of
+      // four, then a rolled one-load-per-trip tail - was six dependent trips.)  The shift K is the first sample, taken inside the
+      // first trip; the accumulation order is the pixel order, as before.
+      bool have_k = false;
+      auto take = [&](const uint4& raw) __attribute__((always_inline)) {
         float f[PC];
         Chunk<T>::unpack(raw, f);
+        if (!have_k) {
+          k0 = f[0];
+#pragma unroll
+          for (int e = 1; e < PC; ++e) if (e == split) k1 = f[e];
+          have_k = true;
+        }
 #pragma unroll
         for (int e = 0; e < PC; ++e) {
           if (e < split) { const float d = f[e] - k0; s0 += d; q0 += d * d; }
           else { const float d = f[e] - k1; s1 += d; q1 += d * d; }
         }
-        ++npix;
+      };
+      for (; pix + 7 * TY < p1; pix += 8 * TY) {
+        uint4 raw[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) raw[u] = load_cat<T>(p, b, pix + u * TY, v);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) take(raw[u]);
+        npix += 8;
+      }
+      for (; pix + 3 * TY < p1; pix += 4 * TY) {
+        uint4 raw[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) raw[u] = load_cat<T>(p, b, pix + u * TY, v);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) take(raw[u]);
+        npix += 4;
+      }
+      if (pix < p1) {
+        uint4 raw[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) raw[u] = load_cat<T>(p, b, min(pix + u * TY, p1 - 1), v);
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          if (pix + u * TY < p1) {
+            take(raw[u]);
+            ++npix;
+          }
+        }
       }
     }
     const float n0 = (float)(npix * split), n1 = (float)(npix * (PC - split));

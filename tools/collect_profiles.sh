@@ -23,28 +23,30 @@ python bench.py --batch 4 --latent 128 --steps 20 --warmup 2 --no-cpu-baseline -
 python bench.py --batch 4 --latent 128 --steps 20 --warmup 2 --attention-fp8 16384 --no-cpu-baseline --no-extras --no-images > $O/bench_config4_b4_l128_fp8attn.json 2>/dev/null
 # round 4: same-box comparisons
 timeout 1500 python tools/yardstick.py --compile --out $O/yardstick.txt > $O/yardstick.log 2>&1
-python tools/ff_bench.py 32768 65536 > $O/ff_bench.txt 2>&1
+# QUICK=1: skip the measurements of kernels that did not change since the round's previous collection (their files stay as they are)
+[ -z "$QUICK" ] && python tools/ff_bench.py 32768 65536 > $O/ff_bench.txt 2>&1
 python tools/tin_bench.py 32768 65536 2>&1 | grep -v amdgpu.ids > $O/tin_bench.txt
-python tools/attn8_bench.py > $O/attn8_bench.txt 2>&1; python tools/attn8_bench.py 4 4096 320 >> $O/attn8_bench.txt 2>&1
-python tools/attn8_acc.py 2>&1 | grep "N=" > $O/attn8_acc.txt
+[ -z "$QUICK" ] && { python tools/attn8_bench.py > $O/attn8_bench.txt 2>&1; python tools/attn8_bench.py 4 4096 320 >> $O/attn8_bench.txt 2>&1; }
+[ -z "$QUICK" ] && python tools/attn8_acc.py 2>&1 | grep "N=" > $O/attn8_acc.txt
 python tools/attn4_bench.py 2>&1 | grep -v amdgpu.ids > $O/attn4_bench.txt
 python tools/ab_forward.py "12=0,14=0,16=0,2=7" "12=3,14=0,16=0,2=7" "12=3,14=1,16=0,2=7" "12=3,14=1,16=3,2=7" "12=3,14=1,16=3,2=0" --rounds 3 > $O/ab_knobs.txt 2>&1
 # round 5: same-box A/B against the round-4 kernels (scratch/lib_r04.so = the library at the first round-5 commit: round-4 kernels + ABI additions)
 [ -f scratch/lib_r04.so ] && { LDMSEG_HIP_LIB=scratch/lib_r04.so python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras --no-images --no-torch-reference --profile-steps 0 > $O/bench_r04_lib_same_box.json 2>/dev/null; python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras --no-images --no-torch-reference --profile-steps 0 > $O/bench_this_lib_same_box.json 2>/dev/null; }
 # round 5: the weight-streaming kernel (opt-in) against igemm_kernel on the small-map shapes, cold weights; the parity-grade modes
-( for i in 45 46 48 52 31 34 35 39; do for ws in 0 0x20001 0x20005 0x20003; do ROT=1 WS=$ws python tools/kbench.py igemm1 $i 2>&1 | grep "M=" | sed "s/^/ws=$ws /"; done; done ) > $O/kbench_ws.txt 2>/dev/null
+[ -z "$QUICK" ] && ( for i in 45 46 48 52 31 34 35 39; do for ws in 0 0x20001 0x20005 0x20003; do ROT=1 WS=$ws python tools/kbench.py igemm1 $i 2>&1 | grep "M=" | sed "s/^/ws=$ws /"; done; done ) > $O/kbench_ws.txt 2>/dev/null
 python tools/fam.py bf16x3 fp32 bf16 2>&1 | grep -v amdgpu.ids > $O/modes_ms_per_forward.txt
 # round 5: the three data-flow restructurings switched on one by one in one process (19: conv2 + conv_shortcut in one launch, 20: ff.net.2 +
-# proj_out chained, 21: upsampler convs as four 2x2 phase convs), and the resnet-tail / upsampler launches against what they replace
-python tools/ab_forward.py "19=0,20=0,21=0" "19=1,20=0,21=0" "19=1,20=1,21=0" "19=1,20=1,21=1" --rounds 3 2>&1 | grep -v amdgpu.ids > $O/ab_round5_knobs.txt
-python tools/xt_bench.py 2>&1 | grep -v amdgpu.ids > $O/xt_bench.txt
+# proj_out chained, 21: upsampler convs as four 2x2 phase convs, 22: the 320-channel transformers' GroupNorm folded into the fused entry),
+# and the resnet-tail / upsampler launches against what they replace
+python tools/ab_forward.py "19=0,20=0,21=0,22=0" "19=1,20=0,21=0,22=0" "19=1,20=1,21=0,22=0" "19=1,20=1,21=1,22=0" "19=1,20=1,21=1,22=1" --rounds 3 2>&1 | grep -v amdgpu.ids > $O/ab_round5_knobs.txt
+[ -z "$QUICK" ] && python tools/xt_bench.py 2>&1 | grep -v amdgpu.ids > $O/xt_bench.txt
 python tools/acc_round5.py 2>&1 | grep -v amdgpu.ids > $O/accuracy_round5.txt
-( for i in 12 29 44; do for v in 0 1; do UP4=$v python tools/kbench.py igemm1 $i 2>/dev/null | grep "M=" | sed "s/^/up4=$v /"; done; done ) > $O/kbench_up4.txt
-[ -f scratch/lib_stamp.so ] && { export LDMSEG_OP_TIMING_NHWC=1; for shape in "320 64 320" "640 32 640" "1280 16 1280" "320 64 320 1" "640 32 640 1"; do LDMSEG_HIP_LIB=scratch/lib_stamp.so python tools/stamps2.py $shape 2>&1 | grep -v amdgpu.ids; done > $O/igemm_stamps.txt; unset LDMSEG_OP_TIMING_NHWC; }
+[ -z "$QUICK" ] && ( for i in 12 29 44; do for v in 0 1; do UP4=$v python tools/kbench.py igemm1 $i 2>/dev/null | grep "M=" | sed "s/^/up4=$v /"; done; done ) > $O/kbench_up4.txt
+[ -z "$QUICK" ] && [ -f scratch/lib_stamp.so ] && { export LDMSEG_OP_TIMING_NHWC=1; for shape in "320 64 320" "640 32 640" "1280 16 1280" "320 64 320 1" "640 32 640 1"; do LDMSEG_HIP_LIB=scratch/lib_stamp.so python tools/stamps2.py $shape 2>&1 | grep -v amdgpu.ids; done > $O/igemm_stamps.txt; unset LDMSEG_OP_TIMING_NHWC; }
 [ -f scratch/lib_r03.so ] && false && { LDMSEG_HIP_LIB=scratch/lib_r03.so python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras --no-images --no-torch-reference --profile-steps 0 > $O/bench_r03_lib_same_box.json 2>/dev/null; }
 python tools/kbench.py gn > $O/kbench_groupnorm.txt 2>&1
 python tools/kbench.py attn > $O/kbench_attention.txt 2>&1
-for u in mfma_lds mfma_lds2 buf_lds valu_trans copy_floor launch_floor barrier_cost mx_probe; do [ -x tools/ubench/bin/$u ] && timeout 300 tools/ubench/bin/$u > $O/ubench_$u.txt 2>&1; done
+[ -z "$QUICK" ] && for u in mfma_lds mfma_lds2 buf_lds valu_trans copy_floor launch_floor barrier_cost mx_probe; do [ -x tools/ubench/bin/$u ] && timeout 300 tools/ubench/bin/$u > $O/ubench_$u.txt 2>&1; done
 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; tail -2 $O/pytest_gpu.log
 find $O -name "*.db" -delete; find $O -name "*kernel_trace.csv" -size +8M -delete
 du -sh $O
