@@ -521,7 +521,7 @@ def main():
             tr3 = TrainerDiffusion(None, unet3, DDIMNoiseScheduler(**SCHED_KW))
             r3 = timed(tr3, B, L, 5)
             r3["whole_step_frac_of_bf16_mfma_peak_over_3"] = r3["image_steps_per_s"] * FLOP_UNET.get(L, FLOP_UNET_L64) / (PEAK_BF16 / 3)
-            r3["note"] = "fp32 storage / norms / softmax, GEMM products = Wl.Xh + Wh.Xl + Wh.Xh on v_mfma_f32_16x16x32_bf16 (attention still on the exact fp32 MFMA)"
+            r3["note"] = "fp32 storage / norms / softmax, GEMM products = Wl.Xh + Wh.Xl + Wh.Xh on v_mfma_f32_16x16x32_bf16 (attention.hip X3: K / V / Q / P split the same way)"
             extras["bf16x3_parity_mode"] = r3
             del unet3, tr3
         for v_ in extras.values():

@@ -55,7 +55,7 @@ extern "C" {
 
 #define LDMSEG_F32 0           /* fp32 storage, exact-f32 MFMA: the parity mode (1e-3 vs torch-CPU) */
 #define LDMSEG_BF16 1          /* bf16 storage + bf16 MFMA, fp32 accumulate/statistics: the perf mode */
-#define LDMSEG_BF16X3 2        /* fp32 storage, norms / softmax / scheduler in fp32, GEMM products on the bf16 MFMAs as hi + lo
+#define LDMSEG_BF16X3 2        /* fp32 storage, norms / softmax / scheduler in fp32, GEMM and attention products on the bf16 MFMAs as hi + lo
                                 * (three MFMAs per product block, fp32 accumulation; relative error per product < 2^-16):
                                 * the parity-grade throughput mode - inside the 1e-3 bound at several times the exact mode's speed */
 
