@@ -109,7 +109,7 @@ def test_noise_ops_index_errors(sched):
 
 
 # ------------------------------------------------------------------ seg-VAE
-@pytest.fixture(scope="module", params=["fp32", "bf16"])
+@pytest.fixture(scope="module", params=["fp32", "bf16", "bf16x3"])
 def vae(request, vae_sd):
     from ldmseg_amd.models import GeneralVAESeg
     return GeneralVAESeg(vae_sd, scaling_factor=0.2, device=DEV, compute_dtype=request.param), request.param
@@ -117,7 +117,7 @@ def vae(request, vae_sd):
 
 def test_vae_vs_reference_golden(golden, vae):
     v, mode = vae
-    tol = 1e-3 if mode == "fp32" else 4e-2
+    tol = 4e-2 if mode == "bf16" else 1e-3          # fp32 and bf16x3 (split-bf16 GEMM products on fp32 storage) are parity-grade
     g = golden("vae.npz")
     assert v.num_parameters == 2023208
     assert (v.downsample_factor, v.interpolation_factor, v.num_latents) == (8, 2, 2)
@@ -134,7 +134,7 @@ def test_vae_vs_reference_golden(golden, vae):
 
 def test_vae_vs_oracle_larger(vae, vae_sd):
     v, mode = vae
-    tol = 1e-3 if mode == "fp32" else 4e-2
+    tol = 4e-2 if mode == "bf16" else 1e-3          # fp32 and bf16x3 (split-bf16 GEMM products on fp32 storage) are parity-grade
     g = torch.Generator().manual_seed(21)
     z = torch.randn(2, 4, 16, 16, generator=g)
     with torch.no_grad():
@@ -514,6 +514,28 @@ def test_sample_vs_oracle(unets, unet_sd, sched_kw):
     assert rel_err(out, ref) < 2e-3
 
 
+def test_sample_bf16x3_vs_oracle(unet_sd, vae_sd, sched_kw):
+    """The whole native loop in the parity-grade throughput mode (compute_dtype="bf16x3": GEMM and attention products as three bf16
+    MFMAs on hi + lo operands, everything else fp32): same bound against the oracle's loop as the exact mode, and the decoded
+    logits of the final latents against the oracle's decoder."""
+    from ldmseg_amd.models import GeneralVAESeg, UNet
+    from ldmseg_amd.schedulers import DDIMNoiseScheduler
+    from ldmseg_amd.trainers import TrainerDiffusion
+    u = UNet(unet_sd, in_channels=12, device=DEV, compute_dtype="bf16x3")
+    v = GeneralVAESeg(vae_sd, scaling_factor=0.2, device=DEV, compute_dtype="bf16x3")
+    tr = TrainerDiffusion(v, u, DDIMNoiseScheduler(**sched_kw))
+    rgb = 0.18215 * torch.randn(2, 4, 16, 16, generator=torch.Generator().manual_seed(4321))
+    out = tr.sample(["", ""], num_inference_steps=4, seed=7, rgb_latents=rgb.to(DEV))
+    so = o_ddim.OracleDDIM(**sched_kw)
+    so.set_timesteps_inference(4)
+    with torch.no_grad():
+        ref = o_sample.sample(lambda inp, t: o_unet.unet_forward(unet_sd, inp, t), so, rgb, seed=7)
+        ref_logits = o_vae.decode(vae_sd, ref * (1 / 0.2), interpolate=True)
+    assert rel_err(out, ref) < 2e-3
+    logits = v.decode(out, interpolate=True, z_scale=1 / 0.2)
+    assert rel_err(logits, ref_logits) < 3e-3
+
+
 def test_unet_8ch_variant_without_self_conditioning(sched_kw):
     """UNet.modify_encoder's 8-channel conv_in (no self-conditioning channel, unet.py:178-233): forward and the
     sampling loop against the oracle."""
@@ -726,14 +748,14 @@ def test_decode_argmax_vs_oracle(vae, vae_sd):
     margin = top2[:, 0] - top2[:, 1]
     ids, prob = v.decode_argmax(z.to(DEV), z_scale=5.0, return_prob=True)
     assert ids.dtype == torch.int64 and ids.shape == (2, 64, 64)
-    clear = margin > (1e-3 if mode == "fp32" else 5e-2) * logits.abs().max()
+    clear = margin > (5e-2 if mode == "bf16" else 1e-3) * logits.abs().max()
     assert clear.float().mean() > 0.3
     assert torch.equal(ids.cpu()[clear], ref_ids[clear])                    # argmax wherever it is not a near-tie
-    assert (ids.cpu() == ref_ids).float().mean() > (0.999 if mode == "fp32" else 0.97)
-    assert (prob.cpu() - ref_prob).abs().max() < (1e-3 if mode == "fp32" else 5e-2)
+    assert (ids.cpu() == ref_ids).float().mean() > (0.97 if mode == "bf16" else 0.999)
+    assert (prob.cpu() - ref_prob).abs().max() < (5e-2 if mode == "bf16" else 1e-3)
     th = float(ref_prob.median())
     ids_t = v.decode_argmax(z.to(DEV), z_scale=5.0, mask_th=th, ignore_label=255)
-    safe = (ref_prob - th).abs() > (1e-3 if mode == "fp32" else 5e-2)
+    safe = (ref_prob - th).abs() > (5e-2 if mode == "bf16" else 1e-3)
     expect = torch.where(ref_prob < th, torch.full_like(ref_ids, 255), ref_ids)
     sel = safe & clear
     assert torch.equal(ids_t.cpu()[sel], expect[sel])

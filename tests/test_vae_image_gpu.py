@@ -19,7 +19,7 @@ def vi_sd():
 @pytest.fixture(scope="module")
 def encoders(vi_sd):
     from ldmseg_amd.models import GeneralVAEImage
-    return {dt: GeneralVAEImage(vi_sd, scaling_factor=0.18215, device="cuda:0", compute_dtype=dt) for dt in ("fp32", "bf16")}
+    return {dt: GeneralVAEImage(vi_sd, scaling_factor=0.18215, device="cuda:0", compute_dtype=dt) for dt in ("fp32", "bf16", "bf16x3")}
 
 
 def test_structure(encoders):
@@ -34,6 +34,17 @@ def test_fp32_parity_vs_oracle(encoders, vi_sd, B, H, W):
     got = encoders["fp32"].encode_moments(x.cuda(), in_mul=2.0, in_add=-1.0).cpu()
     assert got.shape == ref.shape
     assert rel_err(got, ref) <= 1e-3                          # north-star tolerance, fp32 vs torch-CPU
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 64, 64), (2, 128, 64)])
+def test_bf16x3_parity_vs_oracle(encoders, vi_sd, B, H, W):
+    """compute_dtype="bf16x3" (fp32 storage, every GEMM - the single-head attention's S = Q K^T and O = P V included - as three bf16
+    MFMAs on hi + lo operands): the exact mode's bound."""
+    x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(H + W + 1))
+    ref = o_vi.encode_moments(vi_sd, 2 * x - 1)
+    got = encoders["bf16x3"].encode_moments(x.cuda(), in_mul=2.0, in_add=-1.0).cpu()
+    assert got.shape == ref.shape
+    assert rel_err(got, ref) <= 1e-3
 
 
 def test_bf16_close_to_oracle(encoders, vi_sd):
