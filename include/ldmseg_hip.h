@@ -293,17 +293,21 @@ int ldmseg_profile_dump(const char* path);
  * convert instead of the direct e4m3 byte - attention_mx.hip); key 16 = row-local fusion of the 320-channel transformer entry
  * (proj_in -> LayerNorm_1 -> q|k|v in one launch, tproj.hip; bit 0 on, bit 1 loader block rotation; default 3, 0 = the unfused
  * launches); key 2 values: 0 = shipped rule, 7 = the round-3 rule (attention3.hip at head dim 40), 11..14 = attention4.hip forced
- * (8 / 4 waves, lazily tracked / every-tile maxima); key 17 (round 5) = weight-streaming kernel of the small maps (igemm_ws.hip:
- * X through the LDS, every wave's weight rows straight into its registers): bits 0-2 mode (bit 0 on, bit 1 4-wave workgroups, bit 2
- * whole-k-group X buffers with a 3-slot ring), bits 8-19 largest M / 4, bits 20-27 fewest K tiles; default 0 = off (measured level
- * with igemm_kernel); must be set BEFORE a handle is created (the handle then holds the fragment-major weight packing);
+ * (8 / 4 waves, lazily tracked / every-tile maxima); (key 17 was round 5's weight-streaming kernel - measured level with
+ * igemm_kernel, now a record under tools/experiments/);
  * key 19 = resnet conv2 + conv_shortcut as one launch with an extra centre tap (bf16; default 1, 0 = two launches);
  * key 20 = ff.net.2 and proj_out of the 640- / 1280-channel transformers as one chained Linear over [g | h] (bf16; default 1);
  * key 21 = upsampler convs (nearest x2 -> conv3x3) as four 2x2-tap phase convs on the low-resolution map (bf16; default 1);
  * key 22 = the GroupNorm in front of a 320-channel transformer as a statistics pass + a sweep over the fused entry's LDS tile
- * (tproj.hip; bf16, maps of a multiple of 128 pixels; default 1, 0 = a GroupNorm launch of its own, n > 1 = n <= 64 pixel chunks). */
+ * (tproj.hip; bf16, maps of a multiple of 128 pixels; default 1, 0 = a GroupNorm launch of its own, n > 1 = n <= 64 pixel chunks);
+ * key 23 (round 6) = K-sliced bf16 igemm launches reduce their slabs inside the launch when every (tile, slice) item has a
+ * co-resident workgroup: bit 0 on for the 256-row tile forms (where it measured 2-4 % faster than slabs + a finish launch), bit 3 on
+ * for every tile form that has the instantiation (measured 2-20 % slower on the 128-row tiles with 8 slices), bit 1 zero-length
+ * partner poll (every workgroup but a tile's last arriver gives up at once and the last arriver reduces their shares - the path that
+ * needs no co-residency; results are bit-identical), bits 8-23 = poll bound in microseconds (0 = 200); default 1, 0 = slabs + a
+ * finish launch everywhere.  Results are bit-identical in every mode. */
 int ldmseg_debug_set(int key, int value);
-/* current value of a knob (keys 1, 9, 12, 14, 15, 16, 17, 19, 20, 21); key -1 = the shipped default of key 1.  Tests restore through this, never a literal.
+/* current value of a knob (keys 1, 9, 12, 14, 15, 16, 19, 20, 21, 22, 23); key -1 = the shipped default of key 1.  Tests restore through this, never a literal.
  * key 10 = number of cooperative-GroupNorm workgroups that took the self-computing path in ldmseg_op_* launches so far. */
 int ldmseg_debug_get(int key);
 

@@ -21,6 +21,12 @@ int ldmseg_op_conv2d(const float* x, const float* x2, const float* w, const floa
 int ldmseg_op_linear(const float* x, const float* w, const float* bias, const float* resid, const float* rowbias,
                      int rows_per_image, int M, int K, int N, int geglu, int silu, int splits, int dtype, float* out,
                      void* stream);
+/* out = proj_out(h + ff.net.2(g)) + x - the end of a diffusers BasicTransformerBlock inside Transformer2DModel
+ * (/root/reference/ldmseg/models/unet.py:401-425) - as the engines launch it at the 640- / 1280-channel levels: the chained matrix
+ * [Wp W2 | Wp] and bias bp + Wp b2 formed once in fp32 (launch_chain_weights, the create-time kernel), then ONE Linear over [g | h]
+ * with x as the residual.  g [M][4C], h / x / out [M][C], w2 [C][4C], wp [C][C]; b2 / bp may be NULL; C a multiple of 160. */
+int ldmseg_op_chained_ff_out(const float* g, const float* h, const float* x, const float* w2, const float* b2, const float* wp,
+                             const float* bp, int M, int C, int rows_per_image, int dtype, float* out, void* stream);
 /* F.group_norm(cat([x,x2],1), 32, gamma, beta, eps) [+SiLU] */
 int ldmseg_op_groupnorm(const float* x, const float* x2, const float* gamma, const float* beta, int B, int C, int C2,
                         int HW, float eps, int silu, int dtype, float* out, void* stream);

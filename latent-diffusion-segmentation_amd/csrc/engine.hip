@@ -71,6 +71,14 @@ int alloc_gn_sync(void** out) {
   *out = p;
   return 0;
 }
+// a handle's counter region of the in-launch split-K finish (igemm.hip, IgemmParams::cf_ctr), zeroed once
+int alloc_cf_sync(void** out) {
+  void* p = nullptr;
+  if (hipMalloc(&p, igemm_cf_bytes()) != hipSuccess) return fail(LDMSEG_E_OOM, "hipMalloc of the split-K counter region failed");
+  if (hipMemset(p, 0, igemm_cf_bytes()) != hipSuccess) { (void)hipFree(p); return fail(LDMSEG_E_HIP, "split-K counter region init failed"); }
+  *out = p;
+  return 0;
+}
 inline size_t esize(int dt) { return dt == DT_BF16 ? 2 : 4; }
 inline int bke(int dt) { return dt == DT_BF16 ? 64 : 32; }  // channels per 128-B K tile
 
@@ -197,7 +205,6 @@ struct ConvW {
   int N = 0, n_valid = 0, cin_pad = 0, taps = 1, cout = 0;
   void* w_cm = nullptr;   // 3x3 layers that may run on large maps: second packing in channel-major K order (IgemmParams::cm)
   void* w_up4 = nullptr;  // upsampler convs, bf16: [4 phases][N][2x2 taps][C] with the 3x3 taps pre-summed per phase (IgemmParams::up4)
-  void* w_ws = nullptr;   // wide layers with long K: third packing, fragment-major (IgemmParams::Wf, igemm_ws.hip) - small maps
 };
 struct NormW { float* g = nullptr; float* b = nullptr; int C = 0; };
 
@@ -246,10 +253,6 @@ struct Builder {
       TRY(arena->alloc(&out->w_cm, (size_t)Npad * k * k * cin_pad * esize(dt)));
       TRY(launch_repack_conv(w, out->w_cm, Co, Ci, k, k, Npad, cin_pad, dt, s, bke(dt)));
     }
-    if (igemm_ws_wants(Npad, k * k * cin_pad, epi, dt)) {
-      TRY(arena->alloc(&out->w_ws, (size_t)Npad * k * k * cin_pad * esize(dt)));
-      TRY(launch_pack_ws(out->w, out->w_ws, Npad, k * k * cin_pad, s));
-    }
     nparams += (int64_t)Co * Ci * k * k;
     if (has_bias) TRY(f32_copy(prefix + ".bias", Co, &out->bias, Npad));
     else {
@@ -291,6 +294,7 @@ struct Exec {
   void* gn_sync = nullptr;     // the handle's hand-off region of the cooperative GroupNorm (gn_sync_bytes())
   int gn_poll_us = -1;         // >= 0: poll bound of this handle's cooperative norms (backing off, see ldmseg_sample_loop)
   int x3 = 0;                  // fp32 handles in LDMSEG_BF16X3 mode: IgemmParams::x3 of every GEMM launch
+  void* cf_sync = nullptr;     // the handle's counter region of the in-launch split-K finish (igemm_cf_bytes())
   bool dry() const { return ws->dry; }
   // a request beyond the planned workspace (a plan made under other tuning knobs): fail before anything is launched on it
   int ws_ok() const { return ws->overflow ? fail(LDMSEG_E_OOM, "workspace plan exceeded (stale plan): nothing was launched") : 0; }
@@ -304,6 +308,7 @@ struct Exec {
   }
 
   int igemm(IgemmParams& p) {
+    p.cf_ctr = (unsigned long long*)cf_sync;
     if (p.splits == 1) {
       const int sp = igemm_plan_splits(p, dt);
       if (sp > 1) {
@@ -358,7 +363,7 @@ struct Exec {
     p.B = B; p.Hi = x.H; p.Wi = x.W; p.Ho = Ho; p.Wo = Wo;
     p.taps = w.taps; p.stride = stride; p.up = up; p.pad = pad;
     p.M = B * Ho * Wo; p.N = w.N; p.n_valid = w.n_valid;
-    p.W = w.w; p.bias = w.bias; p.Wf = w.w_ws;
+    p.W = w.w; p.bias = w.bias;
     if (w.w_cm && pad < 0 && igemm_conv_cm(x.H * x.W, ctot, w.N, 3, stride, up, dt)) { p.W = w.w_cm; p.cm = 1; }
     p.rowbias = rowbias; p.rb_stride = rb_stride;
     if (resid) { p.resid = resid->p; p.ldr = resid->C; }
@@ -403,7 +408,7 @@ struct Exec {
     p.B = B; p.Hi = x.H; p.Wi = x.W; p.Ho = x.H; p.Wo = x.W;
     p.taps = w.taps; p.stride = 1; p.up = 0; p.pad = -1;
     p.M = B * x.H * x.W; p.N = w.N; p.n_valid = w.n_valid;
-    p.W = w.w; p.bias = w.bias; p.Wf = w.w_ws;
+    p.W = w.w; p.bias = w.bias;
     p.rowbias = rowbias; p.rb_stride = rb_stride;
     p.epi = EPI_STORE;
     const int sp = igemm_plan_splits(p, dt);
@@ -539,6 +544,7 @@ struct ldmseg_unet {
   int temb_cap = 0;                    // steps the buffer holds
   const float* temb_override = nullptr;   // non-null while the loop runs a forward: this step's row (broadcast over the batch)
   void* gn_sync = nullptr;
+  void* cf_sync = nullptr;
   // fused step tail (tail.hip): the sampling loop parks the scheduler step here before a forward; the forward's conv_out
   // launch carries it out (tail_done) and leaves the next forward's packed input in place (xin_ready)
   const StepTail* tail_req = nullptr;
@@ -560,6 +566,7 @@ struct ldmseg_unet {
     if (temb_buf) (void)hipFree(temb_buf);
     if (gn_diag_host) (void)hipHostFree(gn_diag_host);
     if (gn_sync) (void)hipFree(gn_sync);
+    if (cf_sync) (void)hipFree(cf_sync);
   }
 };
 
@@ -943,6 +950,7 @@ int unet_forward_impl(ldmseg_unet* u, const float* a, int Ca, const float* b, in
   Exec ex{ws, u->dt, B, s};
   ex.attn_fp8_min_tokens = u->attn_fp8_min_tokens;
   ex.gn_sync = u->gn_sync;
+  ex.cf_sync = u->cf_sync;
   ex.x3 = u->x3 ? 1 : 0;
   ex.gn_poll_us = u->gn_backoff_calls > 0 ? 2 : -1;
   const int dt = u->dt;
@@ -1134,10 +1142,12 @@ struct ldmseg_vae {
   ConvW convt[4];
   NormW ln[4], dec_gn;
   void* gn_sync = nullptr;
+  void* cf_sync = nullptr;
   ~ldmseg_vae() {
     arena.release();
     if (ws_mem) (void)hipFree(ws_mem);
     if (gn_sync) (void)hipFree(gn_sync);
+    if (cf_sync) (void)hipFree(cf_sync);
   }
 };
 
@@ -1214,6 +1224,7 @@ int vae_decode_impl(ldmseg_vae* v, const float* z, float z_scale, int B, int L, 
   ws->begin(dry, scratch_base);
   Exec ex{ws, v->dt, B, s};
   ex.gn_sync = v->gn_sync;
+  ex.cf_sync = v->cf_sync;
   ex.x3 = v->x3 ? 1 : 0;
   const int dt = v->dt;
   const ldmseg_vae_cfg& c = v->cfg;
@@ -1282,6 +1293,7 @@ int vae_encode_impl(ldmseg_vae* v, const float* x, float mul, float add, int B, 
   ws->begin(dry, scratch_base);
   Exec ex{ws, v->dt, B, s};
   ex.gn_sync = v->gn_sync;
+  ex.cf_sync = v->cf_sync;
   ex.x3 = v->x3 ? 1 : 0;
   const int dt = v->dt;
   const ldmseg_vae_cfg& c = v->cfg;
@@ -1328,10 +1340,12 @@ struct ldmseg_vae_image {
   void* wv = nullptr;       // value projection [512][512], used as the X operand of the V^T GEMM
   float* bv = nullptr;
   void* gn_sync = nullptr;
+  void* cf_sync = nullptr;
   ~ldmseg_vae_image() {
     arena.release();
     if (ws_mem) (void)hipFree(ws_mem);
     if (gn_sync) (void)hipFree(gn_sync);
+    if (cf_sync) (void)hipFree(cf_sync);
   }
 };
 
@@ -1453,6 +1467,7 @@ int klenc_encode_impl(ldmseg_vae_image* v, const float* x, float mul, float add,
   ws->begin(dry, scratch_base);
   Exec ex{ws, v->dt, B, s};
   ex.gn_sync = v->gn_sync;
+  ex.cf_sync = v->cf_sync;
   ex.x3 = v->x3 ? 1 : 0;
   const int dt = v->dt;
   Act xin = ex.new_act(bke(dt), H, W, true);
@@ -1506,6 +1521,7 @@ int ldmseg_unet_create(const ldmseg_unet_cfg* cfg, int n_weights, const char* co
   int r = unet_build(u, wm);
   if (r == 0) r = igemm_warm();
   if (r == 0) r = alloc_gn_sync(&u->gn_sync);
+  if (r == 0) r = alloc_cf_sync(&u->cf_sync);
   if (r != 0) { delete u; return r; }
   *out = u;
   return 0;
@@ -1559,6 +1575,7 @@ int ldmseg_vae_create(const ldmseg_vae_cfg* cfg, int n_weights, const char* cons
   int r = vae_build(v, wm);
   if (r == 0) r = igemm_warm();
   if (r == 0) r = alloc_gn_sync(&v->gn_sync);
+  if (r == 0) r = alloc_cf_sync(&v->cf_sync);
   if (r != 0) { delete v; return r; }
   *out = v;
   return 0;
@@ -1643,6 +1660,7 @@ int ldmseg_vae_image_create(const ldmseg_vae_image_cfg* cfg, int n_weights, cons
   int r = klenc_build(v, wm);
   if (r == 0) r = igemm_warm();
   if (r == 0) r = alloc_gn_sync(&v->gn_sync);
+  if (r == 0) r = alloc_cf_sync(&v->cf_sync);
   if (r != 0) { delete v; return r; }
   *out = v;
   return 0;
@@ -1940,9 +1958,12 @@ int ldmseg_debug_set(int key, int value) {
   if (key == 14) { step_tail_set_mode(value); ++g_plan_epoch; return 0; }
   if (key == 16) { proj_qkv_set_mode(value); ++g_plan_epoch; return 0; }   // proj_in -> norm1 -> q|k|v in one launch (bf16, 320 channels); default 1
   if (key == 15) { attention_mx_set_mode(value); ++g_plan_epoch; return 0; }   // fp8 attention: 1 = scaled MFMAs where the shape allows (default), 0 = unscaled
-  // 17: weight-streaming kernel of the small maps (igemm_ws.hip).  bits 0-2: mode (bit 0 on, bit 1 4-wave workgroups, bit 2 whole-k-group X buffers + 3-slot ring),
-  // bits 8-19: largest M it takes (0: keep), bits 20-27: fewest K tiles (0: keep).  Default 1 | M <= 1024 | >= 40 K tiles
-  if (key == 17) { igemm_ws_set_mode(value & 7, (value >> 8) & 0xfff ? ((value >> 8) & 0xfff) * 4 : 0, (value >> 20) & 0xff); ++g_plan_epoch; return 0; }
+  // (17 was round 5's weight-streaming kernel: measured level with igemm_kernel, now a record under tools/experiments/)
+  // 23: K slices finished inside the igemm launch (round 6).  bit 0: on (256-row tiles, where it measured faster); bit 1: zero-length
+  // partner poll (test: the last arriver reduces the shares of everybody who gave up); bit 3: on every tile form that has the
+  // instantiation; bits 8-23: poll bound in microseconds (0 = 200).  Default 1.
+  if (key == 23) { igemm_set_cf_mode(value); ++g_plan_epoch; return 0; }
+  if (key == 24) { igemm_set_table_override(value); ++g_plan_epoch; return 0; }   // tuning: launch-table override, -1 = off (igemm_set_table_override)
   if (key == 19) { igemm_set_xt_mode(value); ++g_plan_epoch; return 0; }   // 1 (default): resnet conv2 + conv_shortcut as one launch (bf16)
   if (key == 20) { g_ffp_mode = value ? 1 : 0; ++g_plan_epoch; return 0; }
   if (key == 22) { g_gnfold_mode = value < 0 ? 0 : value; ++g_plan_epoch; return 0; }   // GroupNorm folded into the fused transformer entry: 0 off, 1 on, n > 1 on with n pixel chunks
@@ -1962,7 +1983,7 @@ int ldmseg_debug_get(int key) {
   if (key == 14) return step_tail_get_mode();
   if (key == 16) return proj_qkv_get_mode();
   if (key == 15) return attention_mx_get_mode();
-  if (key == 17) return igemm_ws_get_mode();
+  if (key == 23) return igemm_get_cf_mode();
   if (key == 19) return igemm_get_xt_mode();
   if (key == 20) return g_ffp_mode;
   if (key == 22) return g_gnfold_mode;

@@ -125,8 +125,11 @@ constexpr bool epi_stage_dedicated() { return epi_stage_bytes<BM, BN, WAVES_M, W
 // branch it cost every launch of the family 2-5 % (measured; scalar registers and code in the K loop's DMA step).
 // XT: the launch carries an extra centre tap (IgemmParams::src2 / C2 / src3 / C3).  A separate instantiation for the same reason.
 // UP4: conv3x3(nearest_x2(x)) as four 2x2-tap phase convs on the low-resolution map (IgemmParams::up4).  Separate as well.
+// CF: K slices are reduced inside the launch (IgemmParams::cf_ctr; the block behind the item loop).  A separate instantiation like
+// the others: with the finish code merely present every instantiation's register allocation moved by a few VGPRs (three crossed an
+// occupancy step) and whole forwards measured +0.6 %.
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int NST, bool PIPE, int LDR, bool LNF, bool CM = false, bool XT = false,
-          bool UP4 = false>
+          bool UP4 = false, bool CF = false>
 __global__ __launch_bounds__((WAVES_M * WAVES_N + LDR) * 64, (WAVES_M * WAVES_N + LDR) > 8 ? 3 : 2) void igemm_kernel(const IgemmParams p) {   // <=256 regs at 2 waves/SIMD; 12-wave workgroups (8 compute + 4 loader waves) need 3 per SIMD: <=168
   constexpr int NW = WAVES_M * WAVES_N;   // 4 waves (128-row tiles, 2 workgroups/CU) or 8 (256-row tiles)
   static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
@@ -749,6 +752,23 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LDR) * 64, (WAVES_M * WAVES_N 
 
   // split-K item: the raw fp32 accumulators go to this slice's slab
   auto epilogue_partial = [&](int m0, int n0, int zc) __attribute__((always_inline)) {
+    if constexpr (CF) {
+      // cooperative finish: the slabs are read by OTHER workgroups of this launch, so they are published write-through
+      // (sc1: past the non-coherent per-XCD L2s; 16-byte sc1 stores cost what plain ones do) - see cf_finish below
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.partial, 0, (int)p.cf_bytes, 0x00020000);
+      auto row_block = [&](int b, auto bidx) __attribute__((always_inline)) {
+        constexpr int BI = decltype(bidx)::value;
+        const int m = m0 + wm * WTM + b * 16 + (lane & 15);
+        if (m < p.M) {
+          const unsigned off = (unsigned)((((size_t)zc * p.M + m) * p.N + n0 + wn * WTN + lg * 4) * sizeof(float));
+#pragma unroll
+          for (int a = 0; a < NF; ++a)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[a][BI]), rs, off + a * 64, 0, 16);
+        }
+      };
+      static_for<MF>([&](auto bi) __attribute__((always_inline)) { row_block(decltype(bi)::value, bi); });
+      return;
+    }
     auto row_block = [&](int b, auto bidx) __attribute__((always_inline)) {
       constexpr int BI = decltype(bidx)::value;
       const int m = m0 + wm * WTM + b * 16 + (lane & 15);
@@ -975,6 +995,132 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LDR) * 64, (WAVES_M * WAVES_N 
 #pragma unroll
       for (int b = 0; b < MF; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
+  // ================= in-launch cooperative split-K finish (IgemmParams::cf; round 6) =================
+  // The launcher sets cf only when every work item has its own co-resident workgroup (nwork <= grid): this workgroup ran
+  // exactly one item (tile, K slice z) and its slab went out write-through.  Instead of a second launch reading all S slabs
+  // back, the S workgroups of a tile each reduce 1/S of it - rows [z RS, (z+1) RS) - in the finish kernel's slice order (bit
+  // identical to the two-launch path), apply bias / time-embedding row / residual / SiLU and store the output once.
+  // Hand-off (MI355X guide, G16 form R1): sc1 slab stores -> every wave s_waitcnt vmcnt(0) -> barrier -> ONE relaxed agent-scope
+  // ticket add per workgroup; readers poll the ticket word (relaxed, s_sleep) and read the slabs with sc1 loads.  Placement
+  // independent: nothing here assumes which XCD a workgroup runs on.
+  // Progress without co-residency: the poll is bounded; a workgroup that gives up sets its bit in the ticket word's mask
+  // (one fetch_or: if everybody had arrived meanwhile it does its share after all) and leaves; the LAST arriver sees the
+  // mask in its ticket's return value and reduces those shares as well.  Nobody waits for a workgroup that has not started.
+  // Counters are self-cleaning: the last of the S workgroups to leave the tile (second word) zeroes both words.
+  if constexpr (CF) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's slab stores have left the chip's caches
+    __syncthreads();                                          // (loader waves have returned: only compute waves are left)
+    int m0, n0, z, kb_, ke_;
+    item_range(first_item, m0, n0, z, kb_, ke_);
+    const int tile = first_item - z * ntiles;
+    const int S = p.splits;
+    unsigned long long* ctr = p.cf_ctr + 2 * (size_t)tile;
+    volatile unsigned* sflag = (volatile unsigned*)smem;      // the ring is idle now
+    if (tid == 0) {
+      unsigned shares = 0;
+      const unsigned long long old = __hip_atomic_fetch_add(ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((int)(old & 0xffull) + 1 == S) {
+        shares = (1u << z) | (unsigned)(old >> 8);            // last arriver: own share + the shares of those who gave up
+      } else {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (true) {
+          const unsigned long long v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((int)(v & 0xffull) == S) { shares = 1u << z; break; }
+          if (__builtin_amdgcn_s_memrealtime() - t0 >= (unsigned long long)p.cf_poll_ticks) {
+            const unsigned long long o2 = __hip_atomic_fetch_or(ctr, 1ull << (8 + z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((int)(o2 & 0xffull) == S) shares = 1u << z;   // everybody arrived in the meantime: the last arriver did not see the bit
+            else __hip_atomic_fetch_add(p.cf_ctr + p.cf_diag, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // diagnostics: last word of the region
+            break;
+          }
+          __builtin_amdgcn_s_sleep(4);
+        }
+      }
+      // this workgroup will not look at the ticket word again
+      const unsigned long long d = __hip_atomic_fetch_add(ctr + 1, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((int)d + 1 == S) {
+        __hip_atomic_store(ctr, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(ctr + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      sflag[0] = shares;
+    }
+    __syncthreads();
+    const unsigned shares = sflag[0];
+    if (shares) {
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.partial, 0, (int)p.cf_bytes, 0x00020000);
+      const int RS = (BM + S - 1) / S;                        // rows per share
+      constexpr int QPR = BN / 4;                             // channel quads per tile row
+      const unsigned slab = (unsigned)((size_t)p.M * p.N * sizeof(float));
+      const int nq4 = p.n_valid >> 2;
+      // sum of the S slabs of one quad in splitk_finish_kernel's association; SS = compile-time slice count (0: run-time loop)
+      auto reduce_quad = [&](unsigned off, auto ss_tag) __attribute__((always_inline)) -> f32x4 {
+        constexpr int SS = decltype(ss_tag)::value;
+        auto ld = [&](int zz) __attribute__((always_inline)) -> f32x4 {
+          return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off + (unsigned)zz * slab, 0, 16));
+        };
+        if constexpr (SS > 0) {
+          f32x4 L[SS];
+#pragma unroll
+          for (int zz = 0; zz < SS; ++zz) L[zz] = ld(zz);     // all slices in flight together
+          f32x4 v = L[0];
+          int zz = 1;
+#pragma unroll
+          for (; zz + 3 < SS; zz += 4) v += (L[zz] + L[zz + 1]) + (L[zz + 2] + L[zz + 3]);
+          if (zz + 1 < SS) { v += L[zz] + L[zz + 1]; zz += 2; }
+          if (zz < SS) v += L[zz];
+          return v;
+        } else {
+          f32x4 v = ld(0);
+          int zz = 1;
+          for (; zz + 3 < S; zz += 4) {
+            const f32x4 t0 = ld(zz), t1 = ld(zz + 1), t2 = ld(zz + 2), t3 = ld(zz + 3);
+            v += (t0 + t1) + (t2 + t3);
+          }
+          if (zz + 1 < S) { const f32x4 t0 = ld(zz), t1 = ld(zz + 1); v += t0 + t1; zz += 2; }
+          if (zz < S) v += ld(zz);
+          return v;
+        }
+      };
+      auto do_share = [&](int sh, auto ss_tag) __attribute__((always_inline)) {
+        const int r0 = sh * RS;
+        const int r1 = r0 + RS < BM ? r0 + RS : BM;
+        const int nq = (r1 - r0) * QPR;
+        for (int q = tid; q < nq; q += NW * 64) {
+          const int rr = q / QPR, qc = q - rr * QPR;
+          const int m = m0 + r0 + rr, n = n0 + qc * 4;
+          if (m >= p.M || (n >> 2) >= nq4) continue;
+          f32x4 v = reduce_quad((unsigned)(((size_t)m * p.N + n) * sizeof(float)), ss_tag);
+          f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (p.bias) bias = *(const f32x4*)(p.bias + n);
+          v += bias;
+          if (p.rowbias) v += *(const f32x4*)(p.rowbias + (size_t)fd_div(m, p.fd_hwo) * p.rb_stride + n);
+          if (p.resid) {
+            const T* rp = (const T*)p.resid + (size_t)m * p.ldr + n;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += to_f32<T>(rp[r]);
+          }
+          if (p.silu) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
+          }
+          T* o = (T*)p.out + out_row(m) * p.ldo + n;
+          if constexpr (sizeof(T) == 2) {
+            *(uint2*)o = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+          } else {
+            *(f32x4*)o = v;
+          }
+        }
+      };
+      for (int sh = 0; sh < S; ++sh) {
+        if (!((shares >> sh) & 1u)) continue;
+        switch (S) {
+          case 2: do_share(sh, std::integral_constant<int, 2>{}); break;
+          case 4: do_share(sh, std::integral_constant<int, 4>{}); break;
+          case 8: do_share(sh, std::integral_constant<int, 8>{}); break;
+          default: do_share(sh, std::integral_constant<int, 0>{}); break;
+        }
+      }
+    }
+  }
 }
 
 // split-K finish: out = sum_z partial[z] + bias (+rowbias)(+resid), optional SiLU  (EPI_STORE only)
@@ -1073,6 +1219,7 @@ int g_big = kDefaultPolicy;      // bit0: 8-wave 256-row tiles with a 3-stage ri
                      // tiles (+ loader waves on long K); bit5: loader waves on the 256-row tiles (long K / GEGLU)
 
 int g_force_cfg = -1;            // tools/tune_igemm.py: run every launch with this entry of the instantiation list
+int g_cf_mode = 1;               // igemm_set_cf_mode (debug key 23)
 int g_cm_mode = -1;              // igemm_set_cm_mode
 
 // Launch table measured on the MI355X (tools/tune_igemm.py): launch shape -> entry of the instantiation list in run_cfg()
@@ -1083,8 +1230,15 @@ const TunedEntry kTuned[] = {
 #include "igemm_tuned.inc"
     {-1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
 
+int g_table_override = -1;       // igemm_set_table_override (debug key 24)
 const TunedEntry* tuned_lookup(const IgemmParams& p, int dtype) {
   if (g_big != kDefaultPolicy || g_force_cfg >= 0) return nullptr;
+  if (g_table_override >= 0 && p.epi == EPI_STORE && !p.rowstats) {     // tuning: every plain-store launch as if the table held this entry
+    static thread_local TunedEntry e;
+    e = TunedEntry{dtype, p.M, p.N, 0, p.taps, p.stride, p.up, p.epi, 0, g_table_override & 0xff, (g_table_override >> 8) & 0xff};
+    if (e.splits < 1) e.splits = 1;
+    return &e;
+  }
   const int K = p.taps * (p.C0 + p.C1), lnf = p.rowstats ? 1 : 0;
   for (const TunedEntry* e = kTuned; e->dtype >= 0; ++e)
     if (e->M == p.M && e->N == p.N && e->K == K && e->dtype == dtype && e->taps == p.taps && e->stride == p.stride &&
@@ -1093,6 +1247,18 @@ const TunedEntry* tuned_lookup(const IgemmParams& p, int dtype) {
   return nullptr;
 }
 
+// the instantiations that exist with the in-launch finish: bf16, the four tile forms K-sliced launches of the UNet run on
+template <typename T, int BM, int BN, int WM, int WN, int NST, bool PIPE, int LDR, bool LNF, bool CM, bool XT, bool UP4>
+constexpr bool cf_instantiated() {
+  if (sizeof(T) != 2 || BN != 160 || LNF || CM) return false;
+  const bool c0 = BM == 256 && WM == 4 && WN == 2 && NST == 3 && PIPE && LDR == 4;      // entry 0 of the instantiation list
+  const bool c3 = BM == 128 && WM == 2 && WN == 2 && NST == 4 && PIPE && LDR == 4;      // entry 3
+  const bool c4 = BM == 128 && WM == 4 && WN == 2 && NST == 3 && PIPE && LDR == 0;      // entry 4
+  const bool c10 = BM == 64 && WM == 2 && WN == 2 && NST == 4 && PIPE && LDR == 4;      // entry 10
+  if (UP4) return c0 && !XT;
+  if (XT) return c0 || c3 || c4;
+  return c0 || c3 || c4 || c10;
+}
 template <typename T, int BM, int BN, int WM, int WN, int NST = 2, bool PIPE = false, int LDR = 0, bool LNF = false, bool CM = false, bool XT = false,
           bool UP4 = false>
 int run(const IgemmParams& pin, hipStream_t s) {
@@ -1117,15 +1283,40 @@ int run(const IgemmParams& pin, hipStream_t s) {
   const size_t lds = (size_t)NST * (BM + BN) * kRowBytes +
                      (epi_stage_dedicated<BM, BN, WM, WN>() ? epi_stage_bytes<BM, BN, WM, WN>() : 0);
   auto kern = igemm_kernel<T, BM, BN, WM, WN, NST, PIPE, LDR, LNF, CM, XT, UP4>;
+  constexpr bool kHasCf = cf_instantiated<T, BM, BN, WM, WN, NST, PIPE, LDR, LNF, CM, XT, UP4>();
   static bool attr_set[kMaxDev] = {};
   const int dev = cur_dev();
   if (!attr_set[dev]) {
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if constexpr (kHasCf)
+      (void)hipFuncSetAttribute((const void*)igemm_kernel<T, BM, BN, WM, WN, NST, PIPE, LDR, LNF, CM, XT, UP4, true>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set[dev] = true;
   }
+  // Cooperative finish inside the launch: every (tile, K slice) item has a workgroup of its own and all of them fit on the chip
+  // together (one per CU is what every instantiation can hold), the slab set is addressable through one buffer descriptor,
+  // the tile's counters fit the caller's region.  Otherwise: slabs + the finish kernel.
+  p.cf = 0;
+  // (measured per launch shape, tools/cf_bench.py: the in-launch finish wins 2-4 % on the 256-row tiles with 2-4 slices and loses
+  // 2-20 % on the 128-row tiles with 8 - the serial chain drain -> ticket -> poll -> read costs what boundary + finish launch do;
+  // mode bit 3 takes it on every tile form that has the instantiation)
+  if (kHasCf && (BM == 256 || (g_cf_mode & 8)) && p.splits > 1 && p.splits <= 32 && !p.no_finish && p.cf_ctr && (g_cf_mode & 1) && nwork == grid_x && nwork <= num_cus() &&
+      (size_t)p.splits * p.M * p.N * sizeof(float) < ((size_t)1 << 31) && (size_t)(2 * mt * nt + 2) * 8 <= igemm_cf_bytes()) {
+    p.cf = 1;
+    p.cf_diag = (int)(igemm_cf_bytes() / 8) - 1;
+    p.cf_bytes = (unsigned)((size_t)p.splits * p.M * p.N * sizeof(float));
+    const int us = (g_cf_mode >> 8) & 0xffff;
+    p.cf_poll_ticks = (g_cf_mode & 2) ? 0 : (us ? us : 200) * 100;
+  }
   g_last = IgemmDispatch{(int)sizeof(T) == 2 ? DT_BF16 : DT_F32, BM, BN, WM, WN, NST, PIPE ? 1 : 0, LDR,
-                         p.splits > 1 ? p.splits : 1, grid_x, LNF ? 1 : 0, CM ? 1 : 0, 0, XT ? 1 : 0, UP4 ? 1 : 0};
+                         p.splits > 1 ? p.splits : 1, grid_x, LNF ? 1 : 0, CM ? 1 : 0, p.cf, XT ? 1 : 0, UP4 ? 1 : 0};
   if (g_log_on) g_log.insert(igemm_dispatch_name(g_last));
+  if constexpr (kHasCf) {
+    if (p.cf) {
+      hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, NST, PIPE, LDR, LNF, CM, XT, UP4, true>), dim3(grid_x), dim3((WM * WN + LDR) * 64), lds, s, p);
+      return hipGetLastError() == hipSuccess ? 0 : -3;
+    }
+  }
   hipLaunchKernelGGL(kern, dim3(grid_x), dim3((WM * WN + LDR) * 64), lds, s, p);
   if (p.splits > 1 && !p.no_finish) {
     const int nq = p.n_valid >> 2;
@@ -1250,17 +1441,6 @@ int launch_finish(const IgemmParams& pin, hipStream_t s) {
 
 template <typename T>
 int dispatch(const IgemmParams& p, hipStream_t s) {
-  if constexpr (sizeof(T) == 2) {
-    // small maps, long K: the weight-streaming kernel (igemm_ws.hip) writes the slabs
-    if (p.splits > 1 && p.C2 == 0 && g_big == kDefaultPolicy && g_force_cfg < 0 && igemm_ws_ok(p, DT_BF16)) {
-      const int r = launch_igemm_ws(p, s);
-      if (r) return r;
-      const int nw = igemm_ws_waves();
-      g_last = IgemmDispatch{DT_BF16, 128, 32 * nw, 1, nw, 4, 1, 0, p.splits, ((p.M + 127) / 128) * (p.N / (32 * nw)) * p.splits, 0, 0, nw, 0, 0};
-      if (g_log_on) g_log.insert(igemm_dispatch_name(g_last));
-      return p.no_finish ? 0 : launch_finish<T>(p, s);
-    }
-  }
   if (p.up4) {                 // one tile form: 256 x 160 with loader waves (every up4 launch is >= 240 work items, K >= 20 tiles)
     if constexpr (sizeof(T) == 2) return run<T, 256, 160, 4, 2, 3, true, 4, false, false, false, true>(p, s);
     return -2;
@@ -1366,12 +1546,9 @@ IgemmDispatch igemm_last_dispatch() { return g_last; }
 // "igemm<dtype,BM,BN,WM,WN,NST,PIPE,LDR>" + "/splitk" when the launch ran K slices (partial epilogue + finish kernel)
 std::string igemm_dispatch_name(const IgemmDispatch& d) {
   char buf[96];
-  if (d.ws) {
-    std::snprintf(buf, sizeof buf, "igemm_ws<bf16,%d,%d,w%d>/splitk", d.bm, d.bn, d.ws);
-    return buf;
-  }
   std::snprintf(buf, sizeof buf, "igemm<%s,%d,%d,%d,%d,%d,%d,%d%s%s>%s", d.dtype == DT_BF16 ? "bf16" : "f32", d.bm, d.bn, d.wm, d.wn,
-                d.nst, d.pipe, d.ldr, d.lnf ? ",ln" : "", d.cm ? ",cm" : (d.xt ? ",xt" : (d.up4 ? ",up4" : "")), d.splits > 1 ? "/splitk" : "");
+                d.nst, d.pipe, d.ldr, d.lnf ? ",ln" : "", d.cm ? ",cm" : (d.xt ? ",xt" : (d.up4 ? ",up4" : "")),
+                d.splits > 1 ? (d.cf ? "/splitk-cf" : "/splitk") : "");
   return buf;
 }
 void igemm_log_enable(int on) { g_log_on = on != 0; if (on) g_log.clear(); }
@@ -1402,7 +1579,6 @@ int igemm_plan_splits(const IgemmParams& p, int dtype) {
     if (sp > 8) sp = 8;
     return sp < 2 ? 1 : sp;
   }
-  if (p.C2 == 0 && g_big == kDefaultPolicy && g_force_cfg < 0 && igemm_ws_ok(p, dtype)) return igemm_ws_splits(p);
   if (const TunedEntry* e = tuned_lookup(p, dtype)) return e->splits;
   const int bke = dtype == DT_BF16 ? 64 : 32;
   const int bn = p.N % 160 == 0 ? 160 : (p.N % 128 == 0 ? 128 : (p.N % 64 == 0 ? 64 : 32));
@@ -1427,6 +1603,10 @@ int igemm_plan_splits(const IgemmParams& p, int dtype) {
   return splits < 2 ? 1 : splits;
 }
 
+size_t igemm_cf_bytes() { return 64 << 10; }
+void igemm_set_cf_mode(int mode) { g_cf_mode = mode; }
+void igemm_set_table_override(int v) { g_table_override = v; }
+int igemm_get_cf_mode() { return g_cf_mode; }
 size_t igemm_partial_bytes(const IgemmParams& p) {
   return p.splits > 1 ? (size_t)p.splits * p.M * p.N * sizeof(float) : 0;
 }

@@ -69,7 +69,6 @@ struct IgemmParams {
   int N = 0;        // packed rows of W (multiple of the N tile)
   int n_valid = 0;  // real output channels (store mask)
   const void* W = nullptr;       // [N][taps*(C0+C1)] compute dtype, K = (tap, channel)
-  const void* Wf = nullptr;      // the same matrix fragment-major (launch_pack_ws) or null: what igemm_ws_kernel streams
   const float* bias = nullptr;   // [N] (packed order) or null
   const float* rowbias = nullptr;  // [B][rb_stride] per-image bias (time embedding) or null
   int rb_stride = 0;
@@ -90,6 +89,14 @@ struct IgemmParams {
   int splits = 1;
   float* partial = nullptr;
   int no_finish = 0;             // splits > 1: leave the slabs as they are, the caller runs its own finish (launch_finish_groupnorm)
+  // In-launch cooperative finish (round 6): cf_ctr = the caller's counter region (igemm_cf_bytes() bytes, zeroed once; a handle
+  // owns one; launches that share a region must be ordered on one stream) or null = two launches as before.  The launcher decides
+  // per launch (every K slice of every tile must have its own co-resident workgroup) and sets cf / cf_bytes / cf_poll_ticks.
+  unsigned long long* cf_ctr = nullptr;
+  int cf = 0;
+  unsigned cf_bytes = 0;         // bytes of the slab set (buffer range of the write-through stores / loads)
+  int cf_poll_ticks = 20000;     // bound of the partner poll in 100 MHz ticks
+  int cf_diag = 0;               // index of the region's diagnostics word (workgroups that gave up waiting)
   const void* zeros = nullptr;   // >= 16 B of zeros (set by the launcher)
   // set by the launcher: divisions the kernels need (by Ho*Wo, Wo, the number of n tiles / tiles / K slices, K tiles per tap)
   FastDiv fd_hwo, fd_wo, fd_nt, fd_ntiles, fd_nsplit, fd_tpt, fd_mphase;
@@ -104,6 +111,16 @@ int launch_igemm(const IgemmParams& p, int dtype, hipStream_t s);
 size_t igemm_partial_bytes(const IgemmParams& p);
 int igemm_warm();   // per-device lazy state (zero page) created now instead of inside the first launch
 int igemm_plan_splits(const IgemmParams& p, int dtype);
+// cooperative split-K finish inside the igemm launch (IgemmParams::cf_ctr).  Region size; debug key 23: bit 0 = on for the 256-row
+// tile forms (default), bit 3 = on for every tile form with the instantiation, bit 1 = zero-length poll (every workgroup that is not
+// the last arriver gives up: the last arriver reduces the whole tile), bits 8.. = poll bound in microseconds (0 = default 200);
+// fallbacks are counted in the region's last word.
+size_t igemm_cf_bytes();
+void igemm_set_cf_mode(int mode);
+int igemm_get_cf_mode();
+// tuning (debug key 24): >= 0 = every plain-store launch runs entry (v & 0xff) of the instantiation list with (v >> 8) K slices, as
+// if the launch table held that entry for its shape (unlike key 5 this keeps the extra-tap / launch-table routes); -1 = off
+void igemm_set_table_override(int v);
 void attention_set_qf1(int v);    // tuning knob: force 16 query rows per wave
 void igemm_set_tsbuf(void* dev_buf);   // LDMSEG_IGEMM_ABLATE builds only
 void igemm_set_dbg(int flags);
@@ -134,24 +151,12 @@ void igemm_force_cfg(int cfg);   // tuning tool: >= 0 runs every launch with tha
 int igemm_get_dbg();       // current (policy << 8) | ablation flags
 int igemm_default_dbg();   // the shipped value
 // template instantiation + plan of the most recent launch_igemm (test introspection)
-struct IgemmDispatch { int dtype, bm, bn, wm, wn, nst, pipe, ldr, splits, grid, lnf, cm, ws, xt, up4; };   // ws: waves of igemm_ws_kernel (0: igemm_kernel)
+struct IgemmDispatch { int dtype, bm, bn, wm, wn, nst, pipe, ldr, splits, grid, lnf, cm, cf, xt, up4; };   // cf: the K slices were finished inside the launch
 IgemmDispatch igemm_last_dispatch();
 std::string igemm_dispatch_name(const IgemmDispatch& d);
 void igemm_log_enable(int on);      // start (and clear) / stop recording the distinct instantiations launched
 void igemm_log_note(const char* name);   // recorded while logging is on (the fused feed-forward kernel: "mlp_fused<bf16,proj=P>")
 std::string igemm_log_read();       // newline-separated   // ablation flags (profiling only)   // K-loop ring depth (2, 3, 4) - tuning knob
-// igemm_ws.hip (round 5): weight-streaming kernel of the small maps - X through the LDS, every wave's weight rows straight
-// into its registers; writes split-K slabs only (launch_igemm runs the finish).  igemm_ws_ok: the launch shape / mode takes it.
-bool igemm_ws_ok(const IgemmParams& p, int dtype);
-int igemm_ws_splits(const IgemmParams& p);
-int launch_igemm_ws(const IgemmParams& p, hipStream_t s);
-// [N][K] bf16 (K a multiple of 64, N of 16) -> fragment-major: 1 KiB blocks [n / 16][K tile][k-group], lane l of a block =
-// the 16 bytes MFMA lane l wants: row 16 (n / 16) + (l & 15), K elements 64 kt + 32 kg + 8 (l >> 4) .. + 8
-int launch_pack_ws(const void* w_nk, void* out, int N, int K, hipStream_t s);
-bool igemm_ws_wants(int N, int K, int epi, int dtype);     // create time: hold the second packing for this layer?
-int igemm_ws_waves();
-void igemm_ws_set_mode(int mode, int max_m, int min_nk);   // bit 0: on, bit 1: 4-wave workgroups; 0 keeps a threshold
-int igemm_ws_get_mode();
 // tile the launcher would pick (for weight padding): N tile size for a given N.
 int igemm_pick_bn(int n_real, int epi);
 

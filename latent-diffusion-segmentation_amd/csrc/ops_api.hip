@@ -13,6 +13,21 @@
 
 using namespace ldmseg;
 
+// Counter region of the in-launch split-K finish for these handle-less launches: one per device, zeroed once.  The operator
+// entry points are test support and run one launch at a time per device (a handle owns its own region).
+static unsigned long long* op_cf_region() {
+  static unsigned long long* r[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (!r[dev]) {
+    void* q = nullptr;
+    if (hipMalloc(&q, igemm_cf_bytes()) != hipSuccess) return nullptr;
+    (void)hipMemset(q, 0, igemm_cf_bytes());
+    r[dev] = (unsigned long long*)q;
+  }
+  return r[dev];
+}
+
 namespace {
 
 template <typename T>
@@ -120,6 +135,45 @@ int ldmseg_op_conv2d(const float* x, const float* x2, const float* w, const floa
   return launch_igemm(p, dtype, s);
 }
 
+// out = proj_out(h + ff.net.2(g)) + x  (diffusers BasicTransformerBlock.ff.net[2] + residual, Transformer2DModel.proj_out + residual;
+// /root/reference/ldmseg/models/unet.py:401-425) exactly as the bf16 / fp32 engines launch it at the 640- / 1280-channel levels:
+// chained matrix [Wp W2 | Wp] and bias bp + Wp b2 formed in fp32 by launch_chain_weights (the create-time kernel), packed to the
+// compute dtype like TransformerW::ffp, then ONE two-source 1x1 igemm over [g | h] with x as the residual (the launch plan, K slices
+// and instantiation are the engine's).  g [M][4C], h / x / out [M][C], w2 [C][4C], wp [C][C]; b2 / bp may be NULL.
+int ldmseg_op_chained_ff_out(const float* g, const float* h, const float* x, const float* w2, const float* b2, const float* wp,
+                             const float* bp, int M, int C, int rows_per_image, int dtype, float* out, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  Temp t;
+  if (C % bke(dtype) || M < 1 || rows_per_image < 1 || M % rows_per_image) return -2;
+  float* wcat = (float*)t.get((size_t)C * 5 * C * sizeof(float));
+  float* bcat = (float*)t.get((size_t)C * sizeof(float));
+  if (launch_chain_weights(wp, w2, b2, bp, wcat, bcat, C, s)) return -3;
+  const int bn = igemm_pick_bn(C, EPI_STORE);
+  const int Np = rupi(C, bn);
+  if (Np != C) return -2;                                   // (640 and 1280 are multiples of the 160-column tile)
+  void* wpk = t.get((size_t)C * 5 * C * es(dtype));
+  if (launch_repack_conv(wcat, wpk, C, 5 * C, 1, 1, Np, 5 * C, dtype, s)) return -3;
+  void* gp = t.get((size_t)M * 4 * C * es(dtype));
+  void* hp = t.get((size_t)M * C * es(dtype));
+  void* xp = t.get((size_t)M * C * es(dtype));
+  void* op = t.get((size_t)M * C * es(dtype));
+  to_dev_dtype(g, gp, (size_t)M * 4 * C, dtype, s);
+  to_dev_dtype(h, hp, (size_t)M * C, dtype, s);
+  to_dev_dtype(x, xp, (size_t)M * C, dtype, s);
+  IgemmParams p;
+  p.src0 = gp; p.C0 = 4 * C; p.src1 = hp; p.C1 = C;
+  p.B = M / rows_per_image; p.Hi = p.Ho = rows_per_image; p.Wi = p.Wo = 1; p.taps = 1;
+  p.M = M; p.N = Np; p.n_valid = C; p.W = wpk; p.bias = bcat;
+  p.resid = xp; p.ldr = C; p.out = op; p.ldo = C; p.epi = EPI_STORE;
+  p.cf_ctr = op_cf_region();
+  const int sp = igemm_plan_splits(p, dtype);
+  if (sp > 1) { p.splits = sp; p.partial = (float*)t.get((size_t)sp * M * Np * sizeof(float)); }
+  const int r = launch_igemm(p, dtype, s);
+  if (r) return r;
+  from_dev_dtype(op, out, (size_t)M * C, dtype, s);
+  return 0;
+}
+
 // y = [silu]( x @ w^T + bias [+ rowbias[row / rows_per_image]] [+ resid] )   or GEGLU when geglu=1 (w is [2*Nout, K])
 int ldmseg_op_linear(const float* x, const float* w, const float* bias, const float* resid, const float* rowbias,
                      int rows_per_image, int M, int K, int N, int geglu, int silu, int splits, int dtype, float* out,
@@ -158,6 +212,7 @@ int ldmseg_op_linear(const float* x, const float* w, const float* bias, const fl
   p.M = M; p.N = Np; p.n_valid = nout; p.W = wp; p.bias = bp;
   p.rowbias = rowbias; p.rb_stride = N;
   p.resid = rp; p.ldr = N; p.out = op; p.ldo = nout; p.epi = epi; p.silu = silu;
+  p.cf_ctr = op_cf_region();
   if (splits > 1) { p.splits = splits; p.partial = (float*)t.get((size_t)splits * M * Np * sizeof(float)); }
   const int r = launch_igemm(p, dtype, s);
   if (r) return r;
@@ -404,12 +459,7 @@ static int op_igemm_impl(const float* x, const float* x2, const float* w, const 
     if (launch_pack_up4(w, w4, Co, Ci, Np, c0, dtype, s)) return -3;
     p.W = w4; p.taps = 4; p.up = 0; p.up4 = 1; p.Ho = H; p.Wo = W; p.M = 4 * B * H * W; p.cm = 0;
   }
-  const size_t wbytes_ = (size_t)Np * k * k * ct * es(dtype);
-  if (dtype == DT_BF16 && !geglu && !cm && !p.up4 && Np % 256 == 0 && (k * k * ct) % 64 == 0) {     // the fragment-major packing igemm_ws.hip streams
-    void* wf = t.get(wbytes_);
-    if (launch_pack_ws(wp, wf, Np, k * k * ct, s)) return -3;
-    p.Wf = wf;
-  }
+  p.cf_ctr = op_cf_region();
   int sp = splits > 0 ? splits : igemm_plan_splits(p, dtype);
   if (sp > 1) { p.splits = sp; p.partial = (float*)t.get((size_t)sp * p.M * Np * sizeof(float)); }
   if (time_iters > 0 && g_bench_ln && !sp_gt1(sp) && !rowbias) {   // time the folded-LayerNorm instantiation (mean 0, rstd 1, c1 0)
@@ -428,27 +478,19 @@ static int op_igemm_impl(const float* x, const float* x2, const float* w, const 
     const size_t wbytes = p.up4 ? (size_t)16 * Np * c0 * es(dtype) : (size_t)Np * k * k * ct * es(dtype);
     const void* wsrc = p.W;                       // (the up4 launch reads its own packing)
     int rot = g_bench_rot < 1 ? 1 : g_bench_rot;
-    std::vector<const void*> wc(1, wsrc), wfc(1, p.Wf);
+    std::vector<const void*> wc(1, wsrc);
     for (int i = 1; i < rot; ++i) {
       void* c = t.get(wbytes);
       if (!c) break;
       (void)hipMemcpyAsync(c, wsrc, wbytes, hipMemcpyDeviceToDevice, s);
-      const void* cf = nullptr;
-      if (p.Wf) {
-        void* q = t.get(wbytes);
-        if (!q) break;
-        (void)hipMemcpyAsync(q, p.Wf, wbytes, hipMemcpyDeviceToDevice, s);
-        cf = q;
-      }
       wc.push_back(c);
-      wfc.push_back(cf);
     }
     rot = (int)wc.size();
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    for (int i = 0; i < 3; ++i) { p.W = wc[i % rot]; p.Wf = wfc[i % rot]; (void)launch_igemm(p, dtype, s); }
+    for (int i = 0; i < 3; ++i) { p.W = wc[i % rot]; (void)launch_igemm(p, dtype, s); }
     (void)hipEventRecord(e0, s);
-    for (int i = 0; i < time_iters; ++i) { p.W = wc[(i + 3) % rot]; p.Wf = wfc[(i + 3) % rot]; (void)launch_igemm(p, dtype, s); }
+    for (int i = 0; i < time_iters; ++i) { p.W = wc[(i + 3) % rot]; (void)launch_igemm(p, dtype, s); }
     (void)hipEventRecord(e1, s);
     (void)hipEventSynchronize(e1);
     float ms = 0;
@@ -498,6 +540,7 @@ int ldmseg_op_conv3x3_plus_1x1(const float* h, const float* w2, const float* b2,
   p.B = B; p.Hi = p.Ho = H; p.Wi = p.Wo = W; p.taps = 9; p.stride = 1;
   p.M = B * HW; p.N = Np; p.n_valid = Co; p.W = wx; p.bias = bx; p.out = op; p.ldo = Co; p.epi = EPI_STORE;
   if (!igemm_xt_ok(p, dtype)) return -4;
+  p.cf_ctr = op_cf_region();
   const int sp = splits > 0 ? splits : igemm_plan_splits(p, dtype);
   if (sp > 1) { p.splits = sp; p.partial = (float*)t.get((size_t)sp * p.M * Np * sizeof(float)); }
   const int r = launch_igemm(p, dtype, s);

@@ -89,6 +89,7 @@ SIGNATURES = {
     "ldmseg_op_attention_fp8": (_i, [_vp, _i, _i, _i, _i, _vp, _i, C.POINTER(C.c_float), _vp]),
     "ldmseg_op_convt2": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "ldmseg_op_bilinear2x": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "ldmseg_op_chained_ff_out": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "ldmseg_op_igemm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "ldmseg_op_conv3x3_plus_1x1": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i, C.POINTER(C.c_float), _vp]),
     "ldmseg_op_ln_linear": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _i, _vp, _vp]),

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.normpath(os.path.join(HERE, "..", "csrc"))
 INCLUDE = os.path.normpath(os.path.join(HERE, "..", "..", "include"))
 LIB_PATH = os.path.join(HERE, "libldmseg_hip.so")
-SOURCES = ["igemm.hip", "igemm_ws.hip", "tfuse.hip", "tproj.hip", "tail.hip", "norm.hip", "attention.hip", "attention3.hip", "attention4.hip", "attention_fp8.hip", "attention_mx.hip", "misc.hip", "postproc.hip", "sched.hip", "engine.hip", "ops_api.hip"]
+SOURCES = ["igemm.hip", "tfuse.hip", "tproj.hip", "tail.hip", "norm.hip", "attention.hip", "attention3.hip", "attention4.hip", "attention_fp8.hip", "attention_mx.hip", "misc.hip", "postproc.hip", "sched.hip", "engine.hip", "ops_api.hip"]
 EXTRA_FLAGS = {
     "sched.hip": ["-ffp-contract=off"],                       # bit-exact scheduler arithmetic
     "tail.hip": ["-ffp-contract=off"],                        # the fused step tail carries the same arithmetic

@@ -1046,63 +1046,126 @@ def test_step_tail_kernel(L, case):
         assert torch.equal(xin.cpu(), bf16_round(exp)), case
 
 
-# ---- weight-streaming kernel of the small maps (igemm_ws.hip, round 5) ----
+# ---- K slices finished inside the igemm launch (round 6, debug key 23) ----
 # (B, Ci, Ci2, H, Co, k, stride, up, splits, residual, time-embedding row)
-WS_CASES = {
-    "m512_3x3": (8, 1280, 0, 8, 1280, 3, 1, 0, 0, 0, 1),          # the launch it was written for: M = 512, 180 K tiles, 12 slices of 15
-    "m512_res": (8, 1280, 0, 8, 1280, 3, 1, 0, 0, 1, 0),
-    "ragged_m": (3, 320, 0, 8, 256, 3, 1, 0, 0, 1, 1),            # M = 192: the second m tile is half empty, images end inside tiles
-    "ragged_map": (2, 320, 0, 7, 256, 3, 1, 0, 0, 0, 0),          # 7x7 maps: M = 98, rows of several images and padding taps everywhere
-    "stride2": (2, 320, 0, 16, 512, 3, 2, 0, 0, 0, 0),            # downsampler
-    "up": (2, 320, 0, 4, 256, 3, 1, 1, 0, 0, 0),                  # nearest x2 folded into the gather
-    "concat": (2, 320, 192, 8, 256, 3, 1, 0, 0, 0, 1),            # torch.cat partner: the source switches inside a tap
-    "lin_2560": (2, 2560, 0, 8, 256, 1, 1, 0, 0, 1, 0),           # 1x1: 40 K tiles
-    "slices7": (2, 640, 0, 8, 256, 3, 1, 0, 7, 0, 0),             # 90 K tiles over 7 slices: 12 / 13 tiles, none a multiple of four
-    "slices2": (1, 320, 0, 8, 512, 3, 1, 0, 2, 0, 0),             # 45 K tiles over 2 slices (22 / 23)
-    "slices45": (1, 320, 0, 8, 256, 3, 1, 0, 45, 0, 0),           # one K tile per slice: the whole ring is padding
+CF_CASES = {
+    "m512_3x3": (8, 1280, 0, 8, 1280, 3, 1, 0, 0, 0, 1),          # the 8x8 level's conv: M = 512, the launch table's 8 slices on 128-row tiles
+    "m512_res": (8, 1280, 0, 8, 1280, 3, 1, 0, 8, 1, 0),
+    "m2048_s4": (8, 1280, 0, 16, 1280, 3, 1, 0, 0, 0, 1),         # 256-row tiles with loader waves, the table's 4 slices: shares of 64 rows
+    "ragged_m": (3, 320, 0, 8, 320, 3, 1, 0, 4, 1, 1),            # M = 192: the second m tile is half empty, images end inside tiles
+    "ragged_map": (2, 320, 0, 7, 320, 3, 1, 0, 3, 0, 0),          # 7x7 maps: M = 98; three slices (the run-time slice loop)
+    "stride2": (2, 320, 0, 16, 640, 3, 2, 0, 4, 0, 0),            # downsampler
+    "up": (2, 320, 0, 4, 320, 3, 1, 1, 2, 0, 0),                  # nearest x2 folded into the gather (nine-tap form: odd map for up4)
+    "up4": (8, 1280, 0, 8, 1280, 3, 1, 1, 0, 0, 0),               # the 8x8 -> 16x16 upsampler as four phase convs, K slices by the plan (scatter in the finish)
+    "concat": (2, 320, 192, 8, 320, 3, 1, 0, 5, 0, 1),            # torch.cat partner; five slices
+    "lin_2560": (2, 2560, 0, 8, 320, 1, 1, 0, 8, 1, 0),           # 1x1: 40 K tiles
+    "slices7": (2, 640, 0, 8, 320, 3, 1, 0, 7, 0, 0),             # 90 K tiles over 7 slices
+    "narrow_n": (2, 640, 0, 8, 128, 3, 1, 0, 4, 0, 0),            # N = 128 tiles
+    "slices45": (1, 320, 0, 8, 320, 3, 1, 0, 45, 0, 0),           # more slices than the ticket word's mask holds: two launches
 }
 
 
-@pytest.mark.parametrize("waves", [8, 4])
-@pytest.mark.parametrize("case", sorted(WS_CASES))
-def test_weight_streaming_kernel(L, case, waves):
-    """igemm_ws_kernel (X through the LDS, every wave's weight rows straight into its registers, split-K slabs + finish) against
-    F.conv2d on the bf16-rounded operands, on shapes that hit its edges: ragged M, every gather mode, slice lengths that are
-    not a multiple of the four-tile ring, both workgroup forms."""
-    B, Ci, Ci2, H, Co, k, stride, up, splits, use_res, use_rb = WS_CASES[case]
+@pytest.mark.parametrize("dt", [BF16, F32])
+@pytest.mark.parametrize("case", sorted(CF_CASES))
+def test_splitk_finished_inside_the_launch(L, case, dt):
+    """K-sliced launches whose items all fit on the chip at once reduce their slabs inside the launch: every slice workgroup
+    publishes its slab write-through, takes a ticket, and reduces 1 / S of the tile in the finish kernel's slice order.  Against
+    F.conv2d on the rounded operands, and BIT FOR BIT against the two-launch path (key 23 = 0) - with the partner poll at its
+    shipped bound and at zero length (bit 1: every workgroup but the last arriver gives up at once and the last arriver reduces their
+    shares: the path that makes progress without co-residency).  Each mode runs three times on fresh inputs so that a stale
+    cached slab line of the previous launch would show."""
+    B, Ci, Ci2, H, Co, k, stride, up, splits, use_res, use_rb = CF_CASES[case]
     lib = L.lib()
-    saved = lib.ldmseg_debug_get(17)
-    g = torch.Generator().manual_seed(len(case) * 131 + waves)
+    saved = lib.ldmseg_debug_get(23)
+    assert saved == 1
     ct = Ci + Ci2
-    x = torch.randn(B, Ci, H, H, generator=g)
-    x2 = torch.randn(B, Ci2, H, H, generator=g) if Ci2 else None
-    w = torch.randn(Co, ct, k, k, generator=g) / (ct * k * k) ** 0.5
-    b = torch.randn(Co, generator=g)
-    rb = torch.randn(B, Co, generator=g) if use_rb else None
-    xin = bf16_round(torch.cat([x, x2], 1) if Ci2 else x)
-    if up:
-        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
-    ref = F.conv2d(xin, bf16_round(w), b, stride=stride, padding=k // 2)
-    if rb is not None:
-        ref = ref + rb[:, :, None, None]
-    res = torch.randn(ref.shape, generator=g) if use_res else None
-    if res is not None:
-        ref = ref + bf16_round(res)
-    out = torch.empty(ref.shape, device="cuda")
-    dx, dx2, dw, db, dres, drb = dev(x), dev(x2), dev(w), dev(b), dev(res), dev(rb)
+    outs = {}
+    names = {}
     try:
-        # mode: on (| 4-wave workgroups), M <= 4096, >= 1 K tile per launch - the test shapes are smaller than the shipped thresholds
-        assert lib.ldmseg_debug_set(17, (1 | (2 if waves == 4 else 0)) | ((4096 // 4) << 8) | (1 << 20)) == 0
-        r = lib.ldmseg_op_igemm(P(dx), P(dx2), P(dw), P(db), P(dres), P(drb), B, Ci, Ci2, H, H, Co, k, stride, up, 0,
-                                0, splits, BF16, P(out), None)
-        assert r == 0, lib.ldmseg_last_error()
-        torch.cuda.synchronize()
-        name = L.igemm_last_kernel()
+        for mode in (0, 9, 11):                              # off | on for every tile form that has it | + zero-length poll
+            assert lib.ldmseg_debug_set(23, mode) == 0
+            for rep in range(3):
+                g = torch.Generator().manual_seed(len(case) * 131 + rep)
+                x = torch.randn(B, Ci, H, H, generator=g)
+                x2 = torch.randn(B, Ci2, H, H, generator=g) if Ci2 else None
+                w = torch.randn(Co, ct, k, k, generator=g) / (ct * k * k) ** 0.5
+                b = torch.randn(Co, generator=g)
+                rb = torch.randn(B, Co, generator=g) if use_rb else None
+                rnd = bf16_round if dt == BF16 else (lambda t: t)
+                xin = rnd(torch.cat([x, x2], 1) if Ci2 else x)
+                if up:
+                    xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+                ref = F.conv2d(xin, rnd(w), b, stride=stride, padding=k // 2)
+                if rb is not None:
+                    ref = ref + rb[:, :, None, None]
+                res = torch.randn(ref.shape, generator=g) if use_res else None
+                if res is not None:
+                    ref = ref + rnd(res)
+                out = torch.empty(ref.shape, device="cuda")
+                dx, dx2, dw, db, dres, drb = dev(x), dev(x2), dev(w), dev(b), dev(res), dev(rb)
+                r = lib.ldmseg_op_igemm(P(dx), P(dx2), P(dw), P(db), P(dres), P(drb), B, Ci, Ci2, H, H, Co, k, stride, up, 0,
+                                        0, splits, dt, P(out), None)
+                assert r == 0, lib.ldmseg_last_error()
+                torch.cuda.synchronize()
+                names[mode] = L.igemm_last_kernel()
+                assert rel_err(out, ref) < (8e-3 if dt == BF16 else 2e-5), (case, mode, rep, names[mode])
+                outs[mode, rep] = out.cpu()
     finally:
-        lib.ldmseg_debug_set(17, saved | ((1024 // 4) << 8) | (40 << 20))     # (the shipped thresholds; mode 0 = off is the default)
-    assert name.startswith("igemm_ws<") and f"w{waves}>" in name, name
-    assert rel_err(out, ref) < 8e-3, (case, name)
-    assert lib.ldmseg_debug_get(17) == saved
+        lib.ldmseg_debug_set(23, saved)
+    assert "/splitk " in names[0] + " ", names
+    if case in ("m512_3x3", "m512_res", "m2048_s4", "up4") and dt == BF16:   # (instantiated for the bf16 tile forms K-sliced launches of the UNet use)
+        assert "/splitk-cf" in names[9] and "/splitk-cf" in names[11], names
+    elif case == "slices45" or dt == F32:
+        assert "/splitk-cf" not in names[9], names
+    for rep in range(3):
+        assert torch.equal(outs[9, rep], outs[0, rep]), (case, rep, names)
+        assert torch.equal(outs[11, rep], outs[0, rep]), (case, rep, names)
+    assert lib.ldmseg_debug_get(23) == saved
+
+
+# ---- ff.net.2 and proj_out as one chained Linear (round 5's launch, round 6's operator-level test) ----
+@pytest.mark.parametrize("M", [512, 2048, 8192])
+@pytest.mark.parametrize("Cc", [640, 1280])
+def test_chained_ff_out_vs_oracle(L, Cc, M):
+    """proj_out(h + ff.net.2(g)) + x (diffusers BasicTransformerBlock / Transformer2DModel, unet.py:401-425) in fp64 on the bf16-rounded
+    operands and the SEPARATELY rounded matrices W2 and Wp - what the two-GEMM form of the oracle computes - against the engines' one
+    launch over [g | h] with the chained matrix [Wp W2 | Wp] (formed in fp32, rounded to bf16 once) at the 640- / 1280-channel levels'
+    token counts.  Then the bias-only case g = h = 0: bp + Wp b2 + x must come out to fp32 rounding (fp32 launch) / one bf16 rounding
+    (bf16 launch), which pins the chained bias and the residual path on their own."""
+    g_ = torch.Generator().manual_seed(Cc + M)
+    g = torch.randn(M, 4 * Cc, generator=g_) * 0.5
+    h = torch.randn(M, Cc, generator=g_)
+    x = torch.randn(M, Cc, generator=g_)
+    w2 = torch.randn(Cc, 4 * Cc, generator=g_) / (4 * Cc) ** 0.5
+    wp = torch.randn(Cc, Cc, generator=g_) / Cc ** 0.5
+    b2, bp = torch.randn(Cc, generator=g_), torch.randn(Cc, generator=g_)
+    lib = L.lib()
+    dg, dh, dx, dw2, db2, dwp, dbp = dev(g), dev(h), dev(x), dev(w2), dev(b2), dev(wp), dev(bp)
+    D = lambda t: bf16_round(t).double().cuda()
+    ref = (D(h) + D(g) @ D(w2).t() + b2.double().cuda()) @ D(wp).t() + bp.double().cuda() + D(x)
+    out = torch.empty(M, Cc, device="cuda")
+    assert lib.ldmseg_op_chained_ff_out(P(dg), P(dh), P(dx), P(dw2), P(db2), P(dwp), P(dbp), M, Cc, M // 8, BF16, P(out), None) == 0, lib.ldmseg_last_error()
+    torch.cuda.synchronize()
+    name = L.igemm_last_kernel()
+    l2 = float((out.double() - ref).norm() / ref.norm())
+    print(f"chained Linear C={Cc} M={M}: rel-L2 {l2:.2e} max-norm {rel_err(out, ref):.2e}  {name}")
+    assert torch.isfinite(out).all() and l2 <= 6e-3 and rel_err(out, ref) < 3e-2, (Cc, M, l2, name)
+    # fp32 launch on unrounded operands: the chained form is the same function
+    ref32 = (h.double().cuda() + g.double().cuda() @ w2.double().cuda().t() + b2.double().cuda()) @ wp.double().cuda().t() + bp.double().cuda() + x.double().cuda()
+    assert lib.ldmseg_op_chained_ff_out(P(dg), P(dh), P(dx), P(dw2), P(db2), P(dwp), P(dbp), M, Cc, M // 8, F32, P(out), None) == 0
+    torch.cuda.synchronize()
+    assert rel_err(out, ref32) < 2e-5, (Cc, M)
+    # bias only
+    z4, z1 = torch.zeros(M, 4 * Cc, device="cuda"), torch.zeros(M, Cc, device="cuda")
+    bias_ref = bp.double() + wp.double() @ b2.double()
+    assert lib.ldmseg_op_chained_ff_out(P(z4), P(z1), P(dx), P(dw2), P(db2), P(dwp), P(dbp), M, Cc, M // 8, F32, P(out), None) == 0
+    torch.cuda.synchronize()
+    assert rel_err(out, bias_ref.cuda() + x.double().cuda()) < 2e-6, (Cc, M)
+    assert lib.ldmseg_op_chained_ff_out(P(z4), P(z1), P(dx), P(dw2), P(db2), P(dwp), P(dbp), M, Cc, M // 8, BF16, P(out), None) == 0
+    torch.cuda.synchronize()
+    want = bias_ref.float().cuda() + bf16_round(x).cuda()            # fp32 bias + bf16 residual, stored as bf16
+    assert (out - want).abs().max() <= want.abs().max() * 2 ** -8, (Cc, M)
+    assert torch.equal(out, bf16_round(out.cpu()).cuda())
 
 
 # ---- split-bf16 GEMM arithmetic on fp32 operands (compute_dtype "bf16x3", round 5) ----

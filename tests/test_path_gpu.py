@@ -447,6 +447,39 @@ def test_unet_fused_and_unfused_launch_sets_agree(unets):
             lib.ldmseg_debug_set(k, v)
 
 
+def test_unet_splitk_finish_modes_agree(unets):
+    """Round 6: K-sliced bf16 launches on 256-row tiles reduce their slabs inside the launch (debug key 23, default 1; 9 = every tile
+    form that has the instantiation).  Switching it off (slabs + a finish launch) must not move a single bit of the forward - the
+    in-launch finish adds the slices in the finish kernel's order - nor may the zero-length partner poll (bit 1: a tile's last
+    arriver reduces everybody's share).  B = 8: the batch whose launch shapes take the K-sliced tile forms.  The fp32 mode has no
+    such instantiation."""
+    from ldmseg_amd import _lib
+    lib = _lib.lib()
+    assert lib.ldmseg_debug_get(23) == 1
+    x = torch.randn(8, 12, 64, 64, generator=torch.Generator().manual_seed(23)).to(DEV)
+    outs, used = {}, {}
+    try:
+        for mode in (1, 0, 9, 11, 3):
+            assert lib.ldmseg_debug_set(23, mode) == 0
+            _lib.igemm_log(True)
+            try:
+                for rep in range(2):
+                    outs[mode, rep] = unets["bf16"](x, 500).sample.clone()
+                torch.cuda.synchronize()
+                used[mode] = _lib.igemm_log_read()
+            finally:
+                _lib.igemm_log(False)
+    finally:
+        lib.ldmseg_debug_set(23, 1)
+    ncf = {m: sum("/splitk-cf" in n for n in used[m]) for m in used}
+    print("distinct instantiations finishing in-launch:", ncf)
+    assert ncf[0] == 0 and ncf[1] >= 1 and ncf[9] > ncf[1] and ncf[11] == ncf[9], ncf
+    for mode in (1, 0, 9, 11, 3):
+        assert torch.isfinite(outs[mode, 0]).all()
+        assert torch.equal(outs[mode, 0], outs[mode, 1]), mode           # run to run
+        assert torch.equal(outs[mode, 0], outs[0, 0]), mode              # and across modes
+
+
 def test_unet_conv_k_order_modes_agree(unets):
     """The 3x3 convs of the 320- / 640-channel levels hold two weight packings ((tap, channel) and (channel tile, tap,
     channel)); a bf16 launch picks by map size.  Forcing either order everywhere must give the same forward up to rounding
