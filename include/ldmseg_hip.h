@@ -111,10 +111,14 @@ int ldmseg_unet_set_attention_fp8(ldmseg_unet* h, int min_tokens);
  * larger shape does the same lazily. */
 int ldmseg_unet_reserve(ldmseg_unet* h, int B, int L);
 /* Workgroups of this handle's cooperative GroupNorm launches that did not see their partners within the poll bound and
- * computed the partners' statistics themselves since the handle was created (0 on an undisturbed device: the kernel's
- * workgroups are co-resident).  Synchronises.  ldmseg_sample_loop looks at the same counter (asynchronously) and runs the
+ * computed the partners' statistics themselves since the handle was created, launches under the back-off's short bound
+ * excepted (0 on an undisturbed device: the kernel's workgroups are co-resident).  Synchronises.  ldmseg_sample_loop looks at the same counter (asynchronously) and runs the
  * next calls with a short poll bound while it grows.  No reference counterpart (torch's GroupNorm is one kernel). */
 int ldmseg_unet_gn_fallbacks(ldmseg_unet* h, int64_t* count);
+/* ldmseg_sample_loop calls this handle will still run with the short (2 us) partner poll: 8 after a call whose full-bound norms
+ * missed their partners at least 256 times, one less after every call; launches under the short bound do not count, so the
+ * call after the eighth tries the full bound again.  Does not synchronise (the loop reads the counter one call late). */
+int ldmseg_unet_gn_backoff(ldmseg_unet* h, int32_t* calls_left);
 /* bytes of device workspace a forward at (B, L) needs (allocated lazily, grown never shrunk) */
 size_t ldmseg_unet_workspace_bytes(const ldmseg_unet* h, int B, int L);
 /* number of parameters held (815,556,484 for the 12-channel default) */

@@ -205,6 +205,7 @@ struct ConvW {
   int N = 0, n_valid = 0, cin_pad = 0, taps = 1, cout = 0;
   void* w_cm = nullptr;   // 3x3 layers that may run on large maps: second packing in channel-major K order (IgemmParams::cm)
   void* w_up4 = nullptr;  // upsampler convs, bf16: [4 phases][N][2x2 taps][C] with the 3x3 taps pre-summed per phase (IgemmParams::up4)
+  int xt_cin = 0;         // extra-tap packings (ResnetW::conv2x): input channels of the 1x1 part behind the nine taps' columns
 };
 struct NormW { float* g = nullptr; float* b = nullptr; int C = 0; };
 
@@ -375,7 +376,7 @@ struct Exec {
   // resnet tail: out = conv2(h) + conv_shortcut(cat([x, x2])) as one launch (ResnetW::conv2x); false = the launch has no
   // extra-tap form here (fp32, debug key 19 off, a forced tile policy ...): the caller runs the two convs
   bool conv_xt_ok(const ConvW& w, const Act& h, const Act& x, const Act* x2) const {
-    if (!w.w) return false;
+    if (!w.w || x.C + (x2 ? x2->C : 0) != w.xt_cin) return false;      // (a mismatch takes the two-conv path, which reports it)
     IgemmParams p;
     p.C0 = h.C; p.taps = 9; p.N = w.N; p.src2 = x.p ? x.p : (const void*)1; p.C2 = x.C;
     if (x2) { p.src3 = x2->p ? x2->p : (const void*)1; p.C3 = x2->C; }
@@ -383,6 +384,8 @@ struct Exec {
   }
   int conv_xt(const ConvW& w, const Act& h, const Act& x, const Act* x2, Act* out) {
     if (h.C != w.cin_pad) return fail(LDMSEG_E_SHAPE, "conv_xt: channel mismatch");
+    // the weight rows are [9 cout | xt_cin] long: a shortcut input of another width would walk off them
+    if (x.C + (x2 ? x2->C : 0) != w.xt_cin) return fail(LDMSEG_E_SHAPE, "conv_xt: shortcut channel mismatch");
     *out = new_act(w.n_valid, h.H, h.W, true);
     IgemmParams p;
     p.src0 = h.p; p.C0 = h.C;
@@ -586,7 +589,7 @@ int build_resnet(Builder& b, const std::string& p, int cin, int cout, int* temb_
   // residual read of conv2's epilogue disappear (14 resnets of the UNet)
   if (r->has_shortcut && b.dt == DT_BF16 && r->conv2.N == r->shortcut.N && r->conv2.N % 160 == 0 && cin % bke(b.dt) == 0 && cout % bke(b.dt) == 0) {
     ConvW& x = r->conv2x;
-    x.N = r->conv2.N; x.n_valid = r->conv2.n_valid; x.cin_pad = cout; x.taps = 9; x.cout = cout;
+    x.N = r->conv2.N; x.n_valid = r->conv2.n_valid; x.cin_pad = cout; x.taps = 9; x.cout = cout; x.xt_cin = cin;
     TRY(b.arena->alloc(&x.w, (size_t)x.N * (9 * cout + cin) * esize(b.dt)));
     TRY(launch_concat_rows(r->conv2.w, 9 * cout, r->shortcut.w, cin, x.w, x.N, b.dt, b.s));
     void* pb;
@@ -1832,6 +1835,8 @@ int ldmseg_sample_loop(ldmseg_unet* h, const ldmseg_sample_cfg* cfg, float* late
       *h->gn_diag_host = 0;
     }
     const unsigned long long cur = *(volatile unsigned long long*)h->gn_diag_host;     // whatever the last finished copy left
+    // (only launches under the full bound count - norm.hip - so the eight short-bound calls decay unconditionally and the
+    // ninth probes the full bound again)
     if (cur >= h->gn_diag_seen + 256) h->gn_backoff_calls = 8;
     else if (h->gn_backoff_calls > 0) --h->gn_backoff_calls;
     h->gn_diag_seen = cur;
@@ -1868,6 +1873,13 @@ int ldmseg_sample_loop(ldmseg_unet* h, const ldmseg_sample_cfg* cfg, float* late
   }
   if (h->gn_sync && h->gn_diag_host)
     HIP_TRY(hipMemcpyAsync(h->gn_diag_host, gn_sync_diag_ptr(h->gn_sync), sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+  return 0;
+}
+
+int ldmseg_unet_gn_backoff(ldmseg_unet* h, int32_t* calls_left) {
+  g_err.clear();
+  if (!h || !calls_left) return fail(LDMSEG_E_ARG, "null argument");
+  *calls_left = h->gn_backoff_calls;
   return 0;
 }
 

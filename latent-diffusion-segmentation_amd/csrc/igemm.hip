@@ -88,6 +88,21 @@ struct RowInfo {
 #define DBG(p, bit) 0
 #define STAMP(p, slot)
 #endif
+// stamp builds: slot 14 / 15 = the 100 MHz wall clock (s_memrealtime: one counter for the whole device, comparable ACROSS XCDs, unlike
+// s_memtime) at workgroup start / end, slot 5 = the XCD the workgroup ran on (tools/launch_boundary.py)
+#if defined(LDMSEG_IGEMM_ABLATE) || defined(LDMSEG_IGEMM_STAMP)
+#define STAMP_WALL(p, slot)                                                                         \
+  if ((p).ts && threadIdx.x == 0) (p).ts[(size_t)blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memrealtime();
+#define STAMP_XCC(p)                                                                                \
+  if ((p).ts && threadIdx.x == 0) {                                                                 \
+    unsigned xcc_;                                                                                  \
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));                             \
+    (p).ts[(size_t)blockIdx.x * 16 + 5] = (xcc_ & 0xfu) + 1u;                                        \
+  }
+#else
+#define STAMP_WALL(p, slot)
+#define STAMP_XCC(p)
+#endif
 
 template <int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -810,6 +825,8 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LDR) * 64, (WAVES_M * WAVES_N 
   }
   // ---- prologue: NST-1 stream positions in flight, the first one landed ----
   STAMP(p, 0)
+  STAMP_WALL(p, 14)
+  STAMP_XCC(p)
   if (is_ldr) {
     item_setup();
     int issued = 0;
@@ -990,6 +1007,7 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LDR) * 64, (WAVES_M * WAVES_N 
     if (c_item == first_item) { STAMP(p, 3) }
     __syncthreads();   // the staging stage is handed back to the DMA ring
     if (c_item == first_item) { STAMP(p, 4) }
+    if (c_item + G >= nwork) { STAMP_WALL(p, 15) }
 #pragma unroll
     for (int a = 0; a < NF; ++a)
 #pragma unroll

@@ -1163,7 +1163,7 @@ __global__ __launch_bounds__(NT) void gn_coop_kernel(const GNParams p, int GB) {
       if (tid < 2 * GB) s_rec[sx][tid] = v;
     }
     load_raw(split);
-    if (tid == 0) __hip_atomic_fetch_add(p.sync_diag, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0 && p.sync_diag) __hip_atomic_fetch_add(p.sync_diag, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
   }
   if (tid < 2 * GB && !(tid & 1)) {                   // lane g*2 takes group g (fixed split order -> deterministic)
@@ -1303,6 +1303,10 @@ int run_gn(const GNParams& pin, hipStream_t s) {
       p.splits = S;
       p.coop_mode = g_gn_coop_mode;
       p.poll_ticks = (p.poll_us >= 0 ? p.poll_us : g_gn_poll_us) * 100;   // wall_clock64: 100 MHz
+      // a handle that is backing off (its own short bound) does not count what that bound makes it miss: the counter then only
+      // says what FULL-bound launches met, which is what the back-off decision wants to know (with every fallback
+      // counted, 256 of them under the 2 us bound re-armed the back-off on every call and the full bound was never tried again)
+      if (p.poll_us >= 0) p.sync_diag = nullptr;
       p.per = (p.HW + S - 1) / S;
       p.ty = ppi;
       p.fd_aux = fastdiv_make(vpp);

@@ -77,6 +77,20 @@ class UNet(object):
         _lib.check(_lib.lib().ldmseg_unet_set_attention_fp8(self._h, int(min_tokens)), "ldmseg_unet_set_attention_fp8")
         return self
 
+    def gn_fallbacks(self) -> int:
+        """Workgroups of this handle's cooperative GroupNorm launches that computed a missing partner's statistics themselves
+        (full poll bound only; ldmseg_unet_gn_fallbacks).  Synchronises."""
+        n = C.c_int64(0)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().ldmseg_unet_gn_fallbacks(self._h, C.byref(n)), "ldmseg_unet_gn_fallbacks")
+        return int(n.value)
+
+    def gn_backoff(self) -> int:
+        """Sampling-loop calls this handle will still run with the short partner poll (ldmseg_unet_gn_backoff)."""
+        n = C.c_int32(0)
+        _lib.check(_lib.lib().ldmseg_unet_gn_backoff(self._h, C.byref(n)), "ldmseg_unet_gn_backoff")
+        return int(n.value)
+
     def eval(self):
         return self
 

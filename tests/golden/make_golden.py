@@ -271,6 +271,8 @@ def real_coco_golden():
         out[f"resized_sha_{k}"] = np.frombuffer(hashlib.sha256(r_img.tobytes()).digest(), dtype=np.uint8)
         out[f"resized_ids_{k}"] = r_ids
         print(name, img.size, "segments", len(mapping), "void px", int(ignore.sum()))
+    import PIL
+    out["pillow_version"] = np.array(PIL.__version__)     # the resize / JPEG bytes above are this Pillow's; the test is bit-exact only under it
     np.savez_compressed(os.path.join(HERE, "real_coco.npz"), **out)
     print("real_coco.npz ok", os.path.getsize(os.path.join(HERE, "real_coco.npz")), "bytes")
 

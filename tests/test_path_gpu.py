@@ -227,6 +227,26 @@ def test_unet_bf16x3_l64_batch_vs_oracle_and_fp32(unets, unet_sd):
             assert rel_err(out8[i:i + 1], ref) < 1e-3, i
 
 
+@pytest.mark.parametrize("B,Ls,img", [(16, 64, 11), (4, 128, 2)])
+def test_unet_bf16x3_other_configs_vs_oracle(unet_sd, B, Ls, img):
+    """bf16x3 at the other two single-GPU configurations' shapes: one image of the B = 16 / L = 64 batch
+    (configs[3]) and one of the B = 4 / L = 128 batch (configs[4]: 16384-token attention, M = 65536 GEMMs) against its own oracle
+    forward at the north-star 1e-3."""
+    torch.set_num_threads(64)
+    from ldmseg_amd.models import UNet
+    u = UNet(unet_sd, in_channels=12, device=DEV, compute_dtype="bf16x3")
+    g = torch.Generator().manual_seed(1000 * B + Ls)
+    x = torch.randn(B, 12, Ls, Ls, generator=g)
+    t = torch.tensor(377)
+    out = u(x.to(DEV), t).sample
+    assert torch.isfinite(out).all()
+    with torch.no_grad():
+        ref = o_unet.unet_forward(unet_sd, x[img:img + 1], t)
+    e = float((out[img:img + 1].cpu() - ref).norm() / ref.norm())
+    print(f"bf16x3 B={B} L={Ls} image {img}: max-norm {rel_err(out[img:img + 1], ref):.2e} rel-L2 {e:.2e}")
+    assert rel_err(out[img:img + 1], ref) < 1e-3 and e < 2e-4
+
+
 def test_unet_l64_vs_oracle(unets, unet_sd):
     """The BASELINE latent size (L = 64, 512x512 images) against the oracle: B = 1 in fp32 (north-star 1e-3) and bf16,
     then two images of a batch of 8 - the launch shapes and split-K plans of the benchmarked configuration - against
@@ -445,6 +465,42 @@ def test_unet_fused_and_unfused_launch_sets_agree(unets):
     finally:
         for k, v in shipped.items():
             lib.ldmseg_debug_set(k, v)
+
+
+def test_groupnorm_backoff_arms_and_decays(unet_sd, sched_kw):
+    """the sampling loop's cooperative-GroupNorm back-off.  A call whose full-bound norms missed their partners (forced
+    here with debug key 10: every workgroup computes its partners' statistics itself) arms eight calls with the 2 us poll bound; those
+    calls do not count what the short bound makes them miss, so the back-off decays one per call and the ninth call probes the full
+    bound again; on an idle device nothing is missed there and the handle stays at the full bound.  Results are bit-identical in
+    every state; ldmseg_unet_gn_fallbacks / ldmseg_unet_gn_backoff report it."""
+    from ldmseg_amd import _lib
+    from ldmseg_amd.models import UNet
+    from ldmseg_amd.schedulers import DDIMNoiseScheduler
+    from ldmseg_amd.trainers import TrainerDiffusion
+    lib = _lib.lib()
+    u = UNet(unet_sd, in_channels=12, device=DEV, compute_dtype="bf16")
+    tr = TrainerDiffusion(None, u, DDIMNoiseScheduler(**sched_kw))
+    rgb = (0.18215 * torch.randn(2, 4, 64, 64, generator=torch.Generator().manual_seed(5))).to(DEV)
+    run = lambda: tr.sample(["", ""], num_inference_steps=2, seed=9, rgb_latents=rgb)
+    ref = run()
+    torch.cuda.synchronize()
+    base = u.gn_fallbacks()
+    assert u.gn_backoff() == 0
+    try:
+        assert lib.ldmseg_debug_set(10, 1) == 0
+        forced = run()
+        torch.cuda.synchronize()
+    finally:
+        lib.ldmseg_debug_set(10, 0)
+    n1 = u.gn_fallbacks()
+    assert n1 >= base + 256, (base, n1)
+    assert torch.equal(forced, ref) and u.gn_backoff() == 0          # (the loop looks at the counter at the START of a call)
+    for left in (8, 7, 6, 5, 4, 3, 2, 1, 0, 0):
+        out = run()
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref), left
+        assert u.gn_backoff() == left, (left, u.gn_backoff())
+    assert u.gn_fallbacks() == n1                                     # short-bound calls are not counted, the full-bound probe met its partners
 
 
 def test_unet_splitk_finish_modes_agree(unets):

@@ -1,4 +1,4 @@
-"""Per-workgroup s_memtime stamps of one igemm launch (stamp-only build: tools/build_stamp.sh, LDMSEG_HIP_LIB=scratch/lib_stamp.so).
+"""Per-workgroup s_memtime stamps of one igemm launch (stamp-only build: tools/build_stamp.sh, LDMSEG_HIP_LIB=tools/ab/lib_stamp.so).
     python tools/stamps2.py Ci H Co [k] [B]      e.g. 320 64 320   (M = 32768, N = 320, K = 2880)
 Prints, relative to the EARLIEST workgroup start of the launch: when workgroups start, finish their prologue (first tile landed),
 their K loop, their epilogue - i.e. dispatch ramp, prologue, K loop, epilogue, tail of one launch."""
