@@ -309,7 +309,9 @@ int ldmseg_profile_dump(const char* path);
  * for every tile form that has the instantiation (measured 2-20 % slower on the 128-row tiles with 8 slices), bit 1 zero-length
  * partner poll (every workgroup but a tile's last arriver gives up at once and the last arriver reduces their shares - the path that
  * needs no co-residency; results are bit-identical), bits 8-23 = poll bound in microseconds (0 = 200); default 1, 0 = slabs + a
- * finish launch everywhere.  Results are bit-identical in every mode. */
+ * finish launch everywhere.  Results are bit-identical in every mode;
+ * key 24 = tuning: every plain-store igemm launch runs entry (v & 0xff) of the instantiation list with (v >> 8) K slices as if the
+ * launch table held that entry (-1 = off; unlike key 5 the extra-tap / phase-conv routes stay). */
 int ldmseg_debug_set(int key, int value);
 /* current value of a knob (keys 1, 9, 12, 14, 15, 16, 19, 20, 21, 22, 23); key -1 = the shipped default of key 1.  Tests restore through this, never a literal.
  * key 10 = number of cooperative-GroupNorm workgroups that took the self-computing path in ldmseg_op_* launches so far. */

@@ -150,6 +150,23 @@ def test_unet_layer_shape_vs_oracle(L, dt, cfg, case):
     SEEN[(cfg, dt)].add(name.split(" ")[0])
     # bf16: operands rounded identically, the difference is accumulation order + the bf16 rounding of the stored output
     assert rel_err(out, ref) < (8e-3 if dt == BF16 else 1e-4), (cfg, case, name)
+    if "/splitk-cf" in name:
+        # the same instantiation writes plain slabs where the consumer is not the launch itself (resnet conv1 -> norm2 on the small
+        # maps: the fused finish + GroupNorm kernel reads them): compare that form here too - bit for bit with the in-launch finish
+        lib = L.lib()
+        saved = lib.ldmseg_debug_get(23)
+        out2 = torch.empty(ref.shape, device="cuda")
+        try:
+            assert lib.ldmseg_debug_set(23, 0) == 0
+            assert lib.ldmseg_op_igemm(P(dx), P(dx2), P(dw), P(db), P(dres), P(drb), B, Ci, Ci2, H, H, Co, k, stride, up, geglu,
+                                       0, 0, dt, P(out2), None) == 0
+            torch.cuda.synchronize()
+            name2 = L.igemm_last_kernel()
+        finally:
+            lib.ldmseg_debug_set(23, saved)
+        assert name2.split(" ")[0] == name.split(" ")[0].replace("/splitk-cf", "/splitk"), (name, name2)
+        SEEN[(cfg, dt)].add(name2.split(" ")[0])
+        assert torch.equal(out2, out), (cfg, case, name2)
 
 
 LN_SHAPES = [   # (M at B = 8 / L = 64, K = C, N, geglu): norm1 -> q|k|v and norm3 -> ff.net.0.proj of every transformer level
