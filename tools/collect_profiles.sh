@@ -2,7 +2,7 @@
 # Run on the GPU box from the repo root (gpurun): every measurement profiles/ holds for one round, from ONE box.
 #   bash tools/collect_profiles.sh r02     -> gpurun_out/prof_r02/...;  then locally: python tools/import_profiles.py r02
 set -x
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_$TAG; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 BENCH="python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-images --no-extras --no-torch-reference --profile-steps 0"
@@ -30,10 +30,13 @@ python tools/tin_bench.py 32768 65536 2>&1 | grep -v amdgpu.ids > $O/tin_bench.t
 [ -z "$QUICK" ] && python tools/attn8_acc.py 2>&1 | grep "N=" > $O/attn8_acc.txt
 python tools/attn4_bench.py 2>&1 | grep -v amdgpu.ids > $O/attn4_bench.txt
 python tools/ab_forward.py "12=0,14=0,16=0,2=7" "12=3,14=0,16=0,2=7" "12=3,14=1,16=0,2=7" "12=3,14=1,16=3,2=7" "12=3,14=1,16=3,2=0" --rounds 3 > $O/ab_knobs.txt 2>&1
-# round 5: same-box A/B against the round-4 kernels (scratch/lib_r04.so = the library at the first round-5 commit: round-4 kernels + ABI additions)
-[ -f scratch/lib_r04.so ] && { LDMSEG_HIP_LIB=scratch/lib_r04.so python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras --no-images --no-torch-reference --profile-steps 0 > $O/bench_r04_lib_same_box.json 2>/dev/null; python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras --no-images --no-torch-reference --profile-steps 0 > $O/bench_this_lib_same_box.json 2>/dev/null; }
-# round 5: the weight-streaming kernel (opt-in) against igemm_kernel on the small-map shapes, cold weights; the parity-grade modes
-[ -z "$QUICK" ] && ( for i in 45 46 48 52 31 34 35 39; do for ws in 0 0x20001 0x20005 0x20003; do ROT=1 WS=$ws python tools/kbench.py igemm1 $i 2>&1 | grep "M=" | sed "s/^/ws=$ws /"; done; done ) > $O/kbench_ws.txt 2>/dev/null
+# same-box A/B against the previous round's kernels (tools/ab/lib_r05.so = the library of the round-5 HEAD, built from that tree)
+[ -f tools/ab/lib_r05.so ] && { LDMSEG_HIP_LIB=tools/ab/lib_r05.so python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras --no-images --no-torch-reference --profile-steps 0 > $O/bench_r05_lib_same_box.json 2>/dev/null; python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras --no-images --no-torch-reference --profile-steps 0 > $O/bench_this_lib_same_box.json 2>/dev/null; }
+# round 6: K slices finished inside the launch (debug key 23: off | 256-row tiles (shipped) | every tile form that has the instantiation),
+# per launch shape and in whole forwards
+python tools/cf_bench.py 2>&1 | grep -v amdgpu.ids > $O/cf_bench_per_shape.txt
+python tools/ab_forward.py "23=0" "23=1" "23=9" --rounds 3 2>&1 | grep -v amdgpu.ids > $O/ab_round6_knobs.txt
+[ -z "$QUICK" ] && python tools/cf_tune.py 2>&1 | grep -v amdgpu.ids > $O/cf_tune_32x32_candidates.txt
 python tools/fam.py bf16x3 fp32 bf16 2>&1 | grep -v amdgpu.ids > $O/modes_ms_per_forward.txt
 # round 5: the three data-flow restructurings switched on one by one in one process (19: conv2 + conv_shortcut in one launch, 20: ff.net.2 +
 # proj_out chained, 21: upsampler convs as four 2x2 phase convs, 22: the 320-channel transformers' GroupNorm folded into the fused entry),
@@ -42,8 +45,7 @@ python tools/ab_forward.py "19=0,20=0,21=0,22=0" "19=1,20=0,21=0,22=0" "19=1,20=
 [ -z "$QUICK" ] && python tools/xt_bench.py 2>&1 | grep -v amdgpu.ids > $O/xt_bench.txt
 python tools/acc_round5.py 2>&1 | grep -v amdgpu.ids > $O/accuracy_round5.txt
 [ -z "$QUICK" ] && ( for i in 12 29 44; do for v in 0 1; do UP4=$v python tools/kbench.py igemm1 $i 2>/dev/null | grep "M=" | sed "s/^/up4=$v /"; done; done ) > $O/kbench_up4.txt
-[ -z "$QUICK" ] && [ -f scratch/lib_stamp.so ] && { export LDMSEG_OP_TIMING_NHWC=1; for shape in "320 64 320" "640 32 640" "1280 16 1280" "320 64 320 1" "640 32 640 1"; do LDMSEG_HIP_LIB=scratch/lib_stamp.so python tools/stamps2.py $shape 2>&1 | grep -v amdgpu.ids; done > $O/igemm_stamps.txt; unset LDMSEG_OP_TIMING_NHWC; }
-[ -f scratch/lib_r03.so ] && false && { LDMSEG_HIP_LIB=scratch/lib_r03.so python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras --no-images --no-torch-reference --profile-steps 0 > $O/bench_r03_lib_same_box.json 2>/dev/null; }
+[ -f tools/ab/lib_stamp.so ] && { LDMSEG_HIP_LIB=tools/ab/lib_stamp.so LDMSEG_OP_TIMING_NHWC=1 python tools/launch_boundary.py 2>&1 | grep -v amdgpu.ids > $O/launch_boundary_raw.txt; }
 python tools/kbench.py gn > $O/kbench_groupnorm.txt 2>&1
 python tools/kbench.py attn > $O/kbench_attention.txt 2>&1
 [ -z "$QUICK" ] && for u in mfma_lds mfma_lds2 buf_lds valu_trans copy_floor launch_floor barrier_cost mx_probe; do [ -x tools/ubench/bin/$u ] && timeout 300 tools/ubench/bin/$u > $O/ubench_$u.txt 2>&1; done

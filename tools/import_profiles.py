@@ -4,7 +4,7 @@
 import glob, json, os, re, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
 src, dst = os.path.join(ROOT, "gpurun_out", f"prof_{tag}"), os.path.join(ROOT, "profiles")
 
 
@@ -33,7 +33,8 @@ cp("bench_config4_b4_l128_fp8attn.json", "bench_config4_b4_l128_fp8attn.json")
 cp("kbench_groupnorm.txt", "kbench_groupnorm.txt")
 cp("kbench_attention.txt", "kbench_attention.txt")
 for n in ("yardstick.txt", "ff_bench.txt", "tin_bench.txt", "attn8_bench.txt", "attn8_acc.txt", "attn4_bench.txt", "ab_forward_vs_r03.txt", "bench_r03_lib_same_box.json", "ab_knobs.txt",
-          "bench_r04_lib_same_box.json", "bench_this_lib_same_box.json", "kbench_ws.txt", "modes_ms_per_forward.txt", "igemm_stamps.txt",
+          "bench_r04_lib_same_box.json", "bench_r05_lib_same_box.json", "bench_this_lib_same_box.json", "cf_bench_per_shape.txt", "ab_round6_knobs.txt",
+          "cf_tune_32x32_candidates.txt", "launch_boundary_raw.txt", "modes_ms_per_forward.txt", "igemm_stamps.txt",
           "ab_round5_knobs.txt", "xt_bench.txt", "kbench_up4.txt", "accuracy_round5.txt"):
     cp(n, n)
 
