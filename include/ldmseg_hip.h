@@ -284,7 +284,8 @@ int ldmseg_profile_dump(const char* path);
  * igemm launch with that entry of the instantiation list (-1 = off; the launch table and the shape rules are bypassed -
  * tools/tune_igemm.py); keys 6/7 = ldmseg_bench_igemm only: number of weight copies the timing loop rotates over, and
  * whether the timed launch carries a folded LayerNorm; key 8 = GroupNorm kernel choice (0 = shipped, bit 0 = two-launch
- * scheme everywhere, bit 1 = cooperative kernel from 16x16 maps up, bit 2 = two-pass instead of one-pass small-map kernel); key 9 = K order of 3x3 conv launches: -1 = shipped
+ * scheme everywhere, bit 1 = cooperative kernel from 16x16 maps up, bit 2 = two-pass instead of one-pass small-map kernel, bit 5 (round 6) = no
+ * one-workgroup-per-(image, group) kernel on the 16x16 / 32x32 maps); key 9 = K order of 3x3 conv launches: -1 = shipped
  * rule (channel-major on large maps with many input channels), 0 = (tap, channel) everywhere, 1 = (channel tile, tap,
  * channel) wherever the layer holds that packing; key 10 = cooperative GroupNorm hand-off: 1 = every workgroup computes
  * its partners' statistics itself instead of waiting for them (the path a workgroup takes when its partners are not

@@ -1264,6 +1264,98 @@ int g_gn_poll_us = 100;     // bound of the partner poll
 
 int g_gn_variant = 0;   // tuning knob (ldmseg_debug_set key 8): bit0 = no cooperative kernel (64x64 maps on the two-launch path)
 
+// One workgroup per (image, group), the whole slice in the registers of 512 threads (round 6; bf16, one source): no hand-off between
+// workgroups at all - gn_coop_kernel's S splits of an (image, group block) exchange partial statistics through memory (~3 us of a
+// 12 us launch at 32x32 x 640) - and the tensor is still read once and written once.  The price is that a group's channels are not
+// 16-byte aligned, so the slice moves in 8-byte pieces (cpg % 4 == 0) of partial cache lines.  The 4-byte prototype
+// (tools/ubench/gn_group.hip, B = 8): 8.8 against 12.0 us at 32x32 x 640 (20 dwords per thread), but 20.5 against 16.6 us at 64x64 x 320
+// (40 dwords per thread of 4-byte accesses: TA-bound) and far worse beyond - hence the rule in run_gn; the 8-byte form shipped here
+// measures 7.5 us on the first shape.  torch.cat([x0, x1], 1) inputs: an access lies in one source (C0 % 4 == 0), chosen per access.
+// Block b -> image b % B, group b / B: with block b on XCD b % 8 (observed, speed only) all groups of an image share one L2, so every
+// line is fetched into and written back from one L2.  Statistics: two passes over the registers (mean, then centred squares), fixed
+// reduction order (deterministic).  W = dwords per access (1 | 2), NV = accesses per thread.
+template <int NV, int W>
+__global__ __launch_bounds__(512) void gn_group_kernel(const GNParams p, int upp, int stepq, int stepr) {
+  __shared__ float red[8];
+  __shared__ float gb[2][128];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x % p.B, g = blockIdx.x / p.B;
+  const int cpg = p.cpg, C = p.C0 + p.C1;
+  const int total = p.HW * upp;                       // accesses of this (image, group) slice; upp = accesses per pixel
+  typedef unsigned uw __attribute__((ext_vector_type(W)));
+  // torch.cat([x0, x1], 1): access j of a pixel covers channels g cpg + 2 W j ..; C0 is a multiple of 2 W, so an access lies in ONE source.
+  // jsplit = first access of this group that comes from the second source (0: the whole group does, upp: none of it)
+  const int c_lo = g * cpg;
+  const int jsplit = c_lo >= p.C0 ? 0 : (c_lo + cpg <= p.C0 ? upp : (p.C0 - c_lo) / (2 * W));
+  const unsigned* x0 = (const unsigned*)p.src0 + (size_t)b * p.HW * (p.C0 / 2) + (size_t)(c_lo / 2);
+  const unsigned* x1 = (const unsigned*)p.src1 + (ptrdiff_t)b * p.HW * (p.C1 / 2) + (ptrdiff_t)((c_lo - p.C0) / 2);   // (only dereferenced for j >= jsplit; may point below src1 when the group straddles)
+  unsigned* yout = (unsigned*)p.out + (size_t)b * p.HW * (C / 2) + (size_t)g * (cpg / 2);
+  if (tid < cpg) { gb[0][tid] = p.gamma[g * cpg + tid]; gb[1][tid] = p.beta[g * cpg + tid]; }
+  uw v[NV];
+  int pix = tid / upp, j = tid - pix * upp;            // (one division per thread, off the critical path of nothing: 16 loads follow)
+  const int pix0 = pix, j0 = j;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int d = tid + i * 512;
+    const int pc = d < total ? pix : 0, jc = d < total ? j : 0;      // (clamped: a guarded load is a branch and a wait each)
+    v[i] = jc < jsplit ? *(const uw*)(x0 + (size_t)pc * (p.C0 / 2) + jc * W) : *(const uw*)(x1 + (ptrdiff_t)pc * (p.C1 / 2) + jc * W);
+    pix += stepq; j += stepr;
+    if (j >= upp) { j -= upp; ++pix; }
+  }
+  auto wg_sum = [&](float a) __attribute__((always_inline)) -> float {
+    a = wave64_sum(a);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = a;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) t += red[w];
+    return t;
+  };
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    if (tid + i * 512 < total) {
+#pragma unroll
+      for (int e = 0; e < W; ++e) { const unsigned u = v[i][e]; s += bits_f32(u << 16) + bits_f32(u & 0xffff0000u); }
+    }
+  }
+  const float inv_n = (float)p.inv_n;
+  const float mean = wg_sum(s) * inv_n;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    if (tid + i * 512 < total) {
+#pragma unroll
+      for (int e = 0; e < W; ++e) {
+        const unsigned u = v[i][e];
+        const float a = bits_f32(u << 16) - mean, c = bits_f32(u & 0xffff0000u) - mean;
+        q += a * a + c * c;
+      }
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wg_sum(q) * inv_n + p.eps);
+  pix = pix0; j = j0;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    if (tid + i * 512 < total) {
+      uw o;
+#pragma unroll
+      for (int e = 0; e < W; ++e) {
+        const unsigned u = v[i][e];
+        const int c = 2 * (j * W + e);
+        float a = (bits_f32(u << 16) - mean) * rstd * gb[0][c] + gb[1][c];
+        float d = (bits_f32(u & 0xffff0000u) - mean) * rstd * gb[0][c + 1] + gb[1][c + 1];
+        if (p.silu) { a = silu_f(a); d = silu_f(d); }
+        o[e] = pack_bf16x2(a, d);
+      }
+      *(uw*)(yout + (size_t)pix * (C / 2) + j * W) = o;
+    }
+    pix += stepq; j += stepr;
+    if (j >= upp) { j -= upp; ++pix; }
+  }
+}
+
 template <typename T>
 int run_gn(const GNParams& pin, hipStream_t s) {
   constexpr int PC = Chunk<T>::N;
@@ -1318,6 +1410,21 @@ int run_gn(const GNParams& pin, hipStream_t s) {
     p.fd_cpg = fastdiv_make(p.cpg);
     return 1;
   };
+  // round 6: one workgroup per (image, group) with the slice in registers where that slice is small enough for 8-byte pieces to win
+  // (<= 40 dwords per thread and channels per group a multiple of 4; measured at B = 8, kbench gn: 32x32 x 640 12.0 -> 7.5 us (11 norms of a
+  // forward), 32x32 x (640+640) 15.5 -> 12.0, 16x16 x 640 6.1 -> 4.4, 16x16 x 1280 6.4 -> 5.2, 16x16 x (1280+1280) 9.3 -> 6.9, 16x16 x
+  // (1280+640) 10.4 -> 7.5; 8x8 maps level with gn_one_kernel and left there; whole forward -0.07 ms; tuning bit 5 switches it off)
+  if constexpr (sizeof(T) == 2) {
+    const long acc8 = (long)p.HW * (p.cpg / 4);                     // 8-byte accesses per (image, group) slice
+    constexpr int nv_max = 20;
+    if (!(g_gn_variant & 33) && p.HW >= 256 && p.cpg % 4 == 0 && p.cpg <= 128 && p.C0 % 4 == 0 && p.C1 % 4 == 0 && acc8 <= 512L * nv_max &&
+        (long)p.B * p.groups >= 128) {
+      const int upp = p.cpg / 4;                                    // 8-byte accesses per pixel
+      if (acc8 <= 512 * 10) hipLaunchKernelGGL((gn_group_kernel<10, 2>), dim3(p.B * p.groups), dim3(512), 0, s, p, upp, 512 / upp, 512 % upp);
+      else hipLaunchKernelGGL((gn_group_kernel<20, 2>), dim3(p.B * p.groups), dim3(512), 0, s, p, upp, 512 / upp, 512 % upp);
+      return hipGetLastError() == hipSuccess ? 0 : -3;
+    }
+  }
   // the cooperative kernel first from 32x32 maps up (measured at B = 8: 32x32 x 640 13.9 -> 11.7 us, 32x32 x 1920 29.1 -> 18.8 us,
   // 64x64 x 320 22.9 -> 16.3 us against the paths below); tuning bit1 extends it to the 16x16 maps
   const int coop_min_hw = (g_gn_variant & 2) ? 256 : 1024;

@@ -268,6 +268,53 @@ def test_conv_groupnorm_fused_finish(L, dt, case):
     assert rel_err(out, ref) < (8e-3 if dt == BF16 else 2e-4), case
 
 
+@pytest.mark.parametrize("case", [
+    # B, C, C2, HW, eps, silu, channel offset: maps whose (image, group) slice fits 20 dwords per thread of a 512-thread workgroup
+    (8, 640, 0, 1024, 1e-5, 1, 0.5),       # the 32x32 level of the UNet: 11 norms of a B = 8 forward
+    (16, 640, 0, 1024, 1e-6, 0, 0.5),      # batch 16: two workgroups per CU
+    (4, 640, 0, 1024, 1e-5, 1, 0.5),       # the fewest workgroups the rule takes
+    (8, 512, 0, 1156, 1e-5, 1, 0.5),       # 34 x 34, cpg = 16: ragged last access per thread
+    (8, 256, 0, 2500, 1e-6, 0, 0.5),       # 50 x 50, cpg = 8: two accesses per pixel
+    (8, 640, 0, 1024, 1e-5, 0, 1000.0),    # channel mean 1000x the deviation: the statistics are two passes over the registers
+    (8, 1280, 0, 256, 1e-5, 1, 0.5),       # the 16x16 level
+    (8, 1280, 1280, 256, 1e-5, 1, 0.5),    # torch.cat([h, skip]): cpg = 80, every group inside one source
+    (8, 1280, 640, 256, 1e-5, 1, 0.5),     # cpg = 60: group 21 straddles the source boundary
+    (8, 640, 320, 400, 1e-6, 0, 0.5),      # cpg = 30 is not a multiple of 4: the rule declines, the older kernels run (same bounds)
+])
+def test_groupnorm_one_workgroup_per_group(L, case):
+    """Round 6: bf16 maps whose (image, group) slice is small enough run with ONE workgroup per (image, group) - the slice in
+    registers, no hand-off between workgroups (gn_group_kernel, norm.hip), also over torch.cat([x, x2], 1).  Against F.group_norm on
+    the rounded input, against the kernels it replaces on these shapes (tuning bit 5 of debug key 8), deterministic launch after launch."""
+    B, Cc, C2, HW, eps, silu, off = case
+    g = torch.Generator().manual_seed(Cc + HW + B + C2)
+    x = torch.randn(B, Cc, HW, generator=g) * 2 + off
+    x[:, :, : HW // 3] += 3.0
+    x2 = torch.randn(B, C2, HW, generator=g) - 1.0 if C2 else None
+    gamma = 1 + 0.1 * torch.randn(Cc + C2, generator=g)
+    beta = 0.1 * torch.randn(Cc + C2, generator=g)
+    xin = torch.cat([x, x2], 1) if C2 else x
+    ref = F.group_norm(bf16_round(xin).double(), 32, gamma.double(), beta.double(), eps)
+    if silu:
+        ref = F.silu(ref)
+    out = torch.empty(B, Cc + C2, HW, device="cuda")
+    dx, dx2, dg, db = dev(x), dev(x2), dev(gamma), dev(beta)
+    lib = L.lib()
+    outs = {}
+    try:
+        for variant in (0, 32):
+            lib.ldmseg_debug_set(8, variant)
+            for rep in range(2):
+                assert lib.ldmseg_op_groupnorm(P(dx), P(dx2), P(dg), P(db), B, Cc, C2, HW, eps, silu, BF16, P(out), None) == 0
+                torch.cuda.synchronize()
+                outs[variant, rep] = out.cpu()
+    finally:
+        lib.ldmseg_debug_set(8, 0)
+    tol = 8e-3 if off < 10 else 2e-2          # (bf16 inputs around 1000 carry 4 units of rounding each: the reference sees them too)
+    assert rel_err(outs[0, 0], ref) < tol and rel_err(outs[32, 0], ref) < tol, case
+    assert torch.equal(outs[0, 0], outs[0, 1])
+    assert float((outs[0, 0].double() - outs[32, 0].double()).abs().max()) <= 2 ** -7 * float(ref.abs().max()), case   # one bf16 ulp of the largest output
+
+
 @pytest.mark.parametrize("variant", [0, 1])        # cooperative one-pass kernel, and the two-launch path it replaces
 @pytest.mark.parametrize("dt", [F32, BF16])
 @pytest.mark.parametrize("case", [
@@ -332,6 +379,7 @@ def test_groupnorm_cooperative_without_partners(L, dt, case):
         assert lib.ldmseg_op_groupnorm(P(dx), P(dx2), P(dg), P(db), B, Cc, C2, HW, eps, silu, dt, P(out), None) == 0
         torch.cuda.synchronize()
         return out.clone()
+    lib.ldmseg_debug_set(8, 32)                          # (round 6: the 32x32 x 640 map would otherwise take the one-workgroup-per-group kernel)
     base = run()
     assert torch.isfinite(base).all()
     n0 = lib.ldmseg_debug_get(10)
@@ -345,11 +393,16 @@ def test_groupnorm_cooperative_without_partners(L, dt, case):
     finally:
         lib.ldmseg_debug_set(10, 0)
         lib.ldmseg_debug_set(11, 100)
+        lib.ldmseg_debug_set(8, 0)
     # (fp32 at 128 x 128: 64 slabs x 8 splits exceed one workgroup per CU - that shape stays on the two-launch scheme)
     assert n1 > n0 or dt == F32, "the self-computing path did not run"     # (several fp32 shapes are not cooperative)
     for o in forced + hurried:
         assert torch.equal(o, base), case
-    assert torch.equal(run(), base)
+    lib.ldmseg_debug_set(8, 32)
+    try:
+        assert torch.equal(run(), base)
+    finally:
+        lib.ldmseg_debug_set(8, 0)
 
 
 @pytest.mark.parametrize("dt", [F32, BF16])
