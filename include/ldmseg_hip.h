@@ -309,8 +309,10 @@ int ldmseg_profile_dump(const char* path);
  * co-resident workgroup: bit 0 on for the 256-row tile forms (where it measured 2-4 % faster than slabs + a finish launch), bit 3 on
  * for every tile form that has the instantiation (measured 2-20 % slower on the 128-row tiles with 8 slices), bit 1 zero-length
  * partner poll (every workgroup but a tile's last arriver gives up at once and the last arriver reduces their shares - the path that
- * needs no co-residency; results are bit-identical), bits 8-23 = poll bound in microseconds (0 = 200); default 1, 0 = slabs + a
- * finish launch everywhere.  Results are bit-identical in every mode;
+ * needs no co-residency; results are bit-identical), bit 2 = resnet conv1 -> norm2 on the maps whose conv runs on those tiles as
+ * conv (finished in-launch) + GroupNorm instead of slabs + the fused finish-GroupNorm launch (moves where bf16 rounding happens, as on
+ * the maps whose convs are not K-sliced), bits 8-23 = poll bound in microseconds (0 = 200); default 5, 0 = slabs + finish launches
+ * everywhere.  Bits 0 / 1 / 3 never change a result bit;
  * key 24 = tuning: every plain-store igemm launch runs entry (v & 0xff) of the instantiation list with (v >> 8) K slices as if the
  * launch table held that entry (-1 = off; unlike key 5 the extra-tap / phase-conv routes stay). */
 int ldmseg_debug_set(int key, int value);

@@ -415,7 +415,11 @@ struct Exec {
     p.rowbias = rowbias; p.rb_stride = rb_stride;
     p.epi = EPI_STORE;
     const int sp = igemm_plan_splits(p, dt);
-    if (sp < 2 || !finish_groupnorm_ok(B, x.H * x.W, w.n_valid, dt)) {
+    // round 6 (debug key 23 bit 2, default on): where the conv finishes its K slices inside the launch - bf16, 256-row tiles, i.e. the
+    // 16x16 maps at B = 8 - run conv + GroupNorm (gn_group_kernel: 5 us) instead of slabs + the fused finish-GroupNorm launch (16 us):
+    // measured -12 us per forward in one process (7.963 -> 7.951 ms); on the 128-row tiles of the 8x8 maps the fused launch stays
+    const bool conv_then_gn = sp >= 2 && dt == DT_BF16 && (igemm_get_cf_mode() & 5) == 5 && p.M >= 2048 && p.M % 256 == 0;
+    if (sp < 2 || conv_then_gn || !finish_groupnorm_ok(B, x.H * x.W, w.n_valid, dt)) {
       Act h;
       TRY(conv(w, x, nullptr, &h, 1, 0, false, rowbias, rb_stride, nullptr));
       return groupnorm(n, h, nullptr, eps, silu, out);
@@ -1972,8 +1976,9 @@ int ldmseg_debug_set(int key, int value) {
   if (key == 15) { attention_mx_set_mode(value); ++g_plan_epoch; return 0; }   // fp8 attention: 1 = scaled MFMAs where the shape allows (default), 0 = unscaled
   // (17 was round 5's weight-streaming kernel: measured level with igemm_kernel, now a record under tools/experiments/)
   // 23: K slices finished inside the igemm launch (round 6).  bit 0: on (256-row tiles, where it measured faster); bit 1: zero-length
-  // partner poll (test: the last arriver reduces the shares of everybody who gave up); bit 3: on every tile form that has the
-  // instantiation; bits 8-23: poll bound in microseconds (0 = 200).  Default 1.
+  // partner poll (test: the last arriver reduces the shares of everybody who gave up); bit 2: resnet conv1 -> norm2 on the maps whose conv
+  // runs on those tiles as conv (finished in-launch) + GroupNorm instead of slabs + the fused finish-GroupNorm launch; bit 3: in-launch
+  // finish on every tile form that has the instantiation; bits 8-23: poll bound in microseconds (0 = 200).  Default 5.
   if (key == 23) { igemm_set_cf_mode(value); ++g_plan_epoch; return 0; }
   if (key == 24) { igemm_set_table_override(value); ++g_plan_epoch; return 0; }   // tuning: launch-table override, -1 = off (igemm_set_table_override)
   if (key == 19) { igemm_set_xt_mode(value); ++g_plan_epoch; return 0; }   // 1 (default): resnet conv2 + conv_shortcut as one launch (bf16)

@@ -1237,7 +1237,7 @@ int g_big = kDefaultPolicy;      // bit0: 8-wave 256-row tiles with a 3-stage ri
                      // tiles (+ loader waves on long K); bit5: loader waves on the 256-row tiles (long K / GEGLU)
 
 int g_force_cfg = -1;            // tools/tune_igemm.py: run every launch with this entry of the instantiation list
-int g_cf_mode = 1;               // igemm_set_cf_mode (debug key 23)
+int g_cf_mode = 5;               // igemm_set_cf_mode (debug key 23)
 int g_cm_mode = -1;              // igemm_set_cm_mode
 
 // Launch table measured on the MI355X (tools/tune_igemm.py): launch shape -> entry of the instantiation list in run_cfg()

@@ -112,7 +112,7 @@ size_t igemm_partial_bytes(const IgemmParams& p);
 int igemm_warm();   // per-device lazy state (zero page) created now instead of inside the first launch
 int igemm_plan_splits(const IgemmParams& p, int dtype);
 // cooperative split-K finish inside the igemm launch (IgemmParams::cf_ctr).  Region size; debug key 23: bit 0 = on for the 256-row
-// tile forms (default), bit 3 = on for every tile form with the instantiation, bit 1 = zero-length poll (every workgroup that is not
+// tile forms (default, with bit 2: engine.hip conv_groupnorm), bit 3 = on for every tile form with the instantiation, bit 1 = zero-length poll (every workgroup that is not
 // the last arriver gives up: the last arriver reduces the whole tile), bits 8.. = poll bound in microseconds (0 = default 200);
 // fallbacks are counted in the region's last word.
 size_t igemm_cf_bytes();

@@ -1130,7 +1130,7 @@ def test_splitk_finished_inside_the_launch(L, case, dt):
     B, Ci, Ci2, H, Co, k, stride, up, splits, use_res, use_rb = CF_CASES[case]
     lib = L.lib()
     saved = lib.ldmseg_debug_get(23)
-    assert saved == 1
+    assert saved == 5
     ct = Ci + Ci2
     outs = {}
     names = {}

@@ -504,18 +504,20 @@ def test_groupnorm_backoff_arms_and_decays(unet_sd, sched_kw):
 
 
 def test_unet_splitk_finish_modes_agree(unets):
-    """Round 6: K-sliced bf16 launches on 256-row tiles reduce their slabs inside the launch (debug key 23, default 1; 9 = every tile
-    form that has the instantiation).  Switching it off (slabs + a finish launch) must not move a single bit of the forward - the
-    in-launch finish adds the slices in the finish kernel's order - nor may the zero-length partner poll (bit 1: a tile's last
-    arriver reduces everybody's share).  B = 8: the batch whose launch shapes take the K-sliced tile forms.  The fp32 mode has no
-    such instantiation."""
+    """Round 6: K-sliced bf16 launches on 256-row tiles reduce their slabs inside the launch (debug key 23, default 5; bit 3 = every
+    tile form that has the instantiation).  Switching it off (slabs + a finish launch) must not move a single bit of the forward - the
+    in-launch finish adds the slices in the finish kernel's order - nor may the zero-length partner poll (bit 1: a tile's last arriver
+    reduces everybody's share).  Bit 2 (conv1 -> norm2 of the 16x16 maps as conv + GroupNorm instead of the fused finish-GroupNorm
+    launch) moves the point where bf16 rounding happens: compared among its own settings bitwise, against the others by distance.
+    B = 8: the batch whose launch shapes take the K-sliced tile forms.  The fp32 mode has no such instantiation."""
     from ldmseg_amd import _lib
     lib = _lib.lib()
-    assert lib.ldmseg_debug_get(23) == 1
+    assert lib.ldmseg_debug_get(23) == 5
     x = torch.randn(8, 12, 64, 64, generator=torch.Generator().manual_seed(23)).to(DEV)
+    ref32 = unets["fp32"](x, 500).sample.clone()
     outs, used = {}, {}
     try:
-        for mode in (1, 0, 9, 11, 3):
+        for mode in (5, 0, 1, 9, 11, 3, 13, 15, 7, 4):
             assert lib.ldmseg_debug_set(23, mode) == 0
             _lib.igemm_log(True)
             try:
@@ -526,14 +528,22 @@ def test_unet_splitk_finish_modes_agree(unets):
             finally:
                 _lib.igemm_log(False)
     finally:
-        lib.ldmseg_debug_set(23, 1)
+        lib.ldmseg_debug_set(23, 5)
     ncf = {m: sum("/splitk-cf" in n for n in used[m]) for m in used}
     print("distinct instantiations finishing in-launch:", ncf)
-    assert ncf[0] == 0 and ncf[1] >= 1 and ncf[9] > ncf[1] and ncf[11] == ncf[9], ncf
-    for mode in (1, 0, 9, 11, 3):
-        assert torch.isfinite(outs[mode, 0]).all()
+    assert ncf[0] == 0 and ncf[4] == 0 and ncf[1] >= 1 and ncf[9] > ncf[1] and ncf[11] == ncf[9] and ncf[5] >= ncf[1], ncf
+    for key in outs:
+        assert torch.isfinite(outs[key]).all()
+    for mode in (5, 0, 1, 9, 11, 3, 13, 15, 7, 4):
         assert torch.equal(outs[mode, 0], outs[mode, 1]), mode           # run to run
-        assert torch.equal(outs[mode, 0], outs[0, 0]), mode              # and across modes
+    for mode in (1, 9, 11, 3, 4):
+        assert torch.equal(outs[mode, 0], outs[0, 0]), mode              # bit 2 off (or ineffective without bit 0): all one forward
+    for mode in (13, 15, 7):
+        assert torch.equal(outs[mode, 0], outs[5, 0]), mode              # bit 2 on: all one forward
+    l2 = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    e, base, now = l2(outs[5, 0], outs[0, 0]), l2(outs[0, 0], ref32), l2(outs[5, 0], ref32)
+    print(f"key 23 bit 2: bf16 vs bit-2-off {e:.2e}; vs fp32 {base:.2e} -> {now:.2e}")
+    assert 0 < e < 3e-2 and now < 1.5 * base + 1e-3
 
 
 def test_unet_conv_k_order_modes_agree(unets):
