@@ -115,6 +115,10 @@ int ldmseg_unet_reserve(ldmseg_unet* h, int B, int L);
  * excepted (0 on an undisturbed device: the kernel's workgroups are co-resident).  Synchronises.  ldmseg_sample_loop looks at the same counter (asynchronously) and runs the
  * next calls with a short poll bound while it grows.  No reference counterpart (torch's GroupNorm is one kernel). */
 int ldmseg_unet_gn_fallbacks(ldmseg_unet* h, int64_t* count);
+/* Workgroups of this handle's K-sliced GEMM launches that gave up waiting for the other slices of their tile (poll bound 200 us) and
+ * left their share of the reduction to the tile's last arriver, since the handle was created (0 on an undisturbed device).  Results
+ * are the same either way; the counter says whether something else is holding CUs.  Synchronises.  No reference counterpart. */
+int ldmseg_unet_cf_fallbacks(ldmseg_unet* h, int64_t* count);
 /* ldmseg_sample_loop calls this handle will still run with the short (2 us) partner poll: 8 after a call whose full-bound norms
  * missed their partners at least 256 times, one less after every call; launches under the short bound do not count, so the
  * call after the eighth tries the full bound again.  Does not synchronise (the loop reads the counter one call late). */

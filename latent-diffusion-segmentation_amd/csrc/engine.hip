@@ -1880,6 +1880,19 @@ int ldmseg_sample_loop(ldmseg_unet* h, const ldmseg_sample_cfg* cfg, float* late
   return 0;
 }
 
+int ldmseg_unet_cf_fallbacks(ldmseg_unet* h, int64_t* count) {
+  g_err.clear();
+  if (!h || !count) return fail(LDMSEG_E_ARG, "null argument");
+  DeviceGuard dg(h->cfg.device);
+  unsigned long long n = 0;
+  if (h->cf_sync) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(&n, (const unsigned long long*)h->cf_sync + igemm_cf_bytes() / 8 - 1, sizeof n, hipMemcpyDeviceToHost));
+  }
+  *count = (int64_t)n;
+  return 0;
+}
+
 int ldmseg_unet_gn_backoff(ldmseg_unet* h, int32_t* calls_left) {
   g_err.clear();
   if (!h || !calls_left) return fail(LDMSEG_E_ARG, "null argument");

@@ -63,6 +63,7 @@ SIGNATURES = {
     "ldmseg_unet_set_attention_fp8": (_i, [_vp, _i]),
     "ldmseg_unet_gn_fallbacks": (_i, [_vp, _vp]),
     "ldmseg_unet_gn_backoff": (_i, [_vp, _vp]),
+    "ldmseg_unet_cf_fallbacks": (_i, [_vp, _vp]),
     "ldmseg_sample_loop": (_i, [_vp, C.POINTER(SampleCfg), _vp, _vp, _i, _i, _vp, _vp]),
     "ldmseg_vae_image_create": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
     "ldmseg_vae_image_destroy": (None, [_vp]),

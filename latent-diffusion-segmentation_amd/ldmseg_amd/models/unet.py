@@ -85,6 +85,14 @@ class UNet(object):
             _lib.check(_lib.lib().ldmseg_unet_gn_fallbacks(self._h, C.byref(n)), "ldmseg_unet_gn_fallbacks")
         return int(n.value)
 
+    def cf_fallbacks(self) -> int:
+        """Workgroups of this handle's K-sliced GEMM launches that gave up waiting for their tile's other slices and left their share
+        to the last arriver (ldmseg_unet_cf_fallbacks; 0 on an undisturbed device).  Synchronises."""
+        n = C.c_int64(0)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().ldmseg_unet_cf_fallbacks(self._h, C.byref(n)), "ldmseg_unet_cf_fallbacks")
+        return int(n.value)
+
     def gn_backoff(self) -> int:
         """Sampling-loop calls this handle will still run with the short partner poll (ldmseg_unet_gn_backoff)."""
         n = C.c_int32(0)

@@ -77,6 +77,48 @@ __global__ __launch_bounds__(512) void gn_group_k(const unsigned* __restrict__ x
   }
 }
 
+
+// Timing probe: the 64x64 x 320 map as 16 slices of TWO groups (20 channels = 40 bytes per pixel, 8-byte accesses), NT threads per
+// workgroup, B * 16 workgroups.  Statistics are taken over the pair (wrong as a GroupNorm, right as a cost model).
+template <int NV, int NT>
+__global__ __launch_bounds__(NT) void gn_pair_k(const uint2* __restrict__ x, uint2* __restrict__ y, int B, int HW, int C, int upp, int stepq, int stepr) {
+  __shared__ float red[32];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x % B, g = blockIdx.x / B;
+  const int total = HW * upp;
+  const size_t base = (size_t)b * HW * (C / 4) + (size_t)g * upp;     // in uint2
+  uint2 v[NV];
+  int pix = tid / upp, j = tid - pix * upp;
+  const int pix0 = pix, j0 = j;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int d = tid + i * NT;
+    v[i] = x[base + (size_t)(d < total ? pix : 0) * (C / 4) + (d < total ? j : 0)];
+    pix += stepq; j += stepr;
+    if (j >= upp) { j -= upp; ++pix; }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) s += __builtin_bit_cast(float, v[i].x << 16) + __builtin_bit_cast(float, v[i].y & 0xffff0000u);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if ((tid & 63) == 0) red[tid >> 6] = s;
+  __syncthreads();
+  float t = 0.f;
+  for (int w = 0; w < NT / 64; ++w) t += red[w];
+  const float mean = t / (float)(total * 4);
+  pix = pix0; j = j0;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int d = tid + i * NT;
+    uint2 o = v[i];
+    o.x ^= (unsigned)(mean > 1e30f);
+    if (d < total) y[base + (size_t)pix * (C / 4) + j] = o;
+    pix += stepq; j += stepr;
+    if (j >= upp) { j -= upp; ++pix; }
+  }
+}
+
 static float bf2f(unsigned short h) { unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; }
 
 int main() {
@@ -135,6 +177,28 @@ int main() {
     }
     printf("B=%2d HW=%4d C=%4d (%5.1f MB, %3d dwords per thread): %6.1f us warm (%4.2f TB/s r+w)  %6.1f us cold   max |err| vs host %.3g\n", sh.B, sh.HW, sh.C,
            bytes / 1048576.0, nv, ms[0], 2.0 * bytes / ms[0] * 1e-6, ms[1], maxerr);
+  }
+
+  {  // pair probe
+    const int B = 8, HW = 4096, C = 320, upp = 5;
+    for (int nt : {512, 1024}) {
+      float msb[2];
+      for (int cold = 0; cold < 2; ++cold) {
+        const int iters = 64;
+        for (int rep = 0; rep < 2; ++rep) {
+          (void)hipEventRecord(e0);
+          for (int it = 0; it < iters; ++it) {
+            char* sp = buf + (cold ? (size_t)(it % NB) * 2 * maxb : 0);
+            if (nt == 512) hipLaunchKernelGGL((gn_pair_k<40, 512>), dim3(B * 16), dim3(512), 0, 0, (const uint2*)sp, (uint2*)(sp + maxb), B, HW, C, upp, 512 / upp, 512 % upp);
+            else hipLaunchKernelGGL((gn_pair_k<20, 1024>), dim3(B * 16), dim3(1024), 0, 0, (const uint2*)sp, (uint2*)(sp + maxb), B, HW, C, upp, 1024 / upp, 1024 % upp);
+          }
+          (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+          (void)hipEventElapsedTime(&msb[cold], e0, e1);
+          msb[cold] = msb[cold] * 1e3f / iters;
+        }
+      }
+      printf("pair probe 64x64 x 320 as 16 two-group slices, %4d threads x 128 workgroups: %6.1f us warm  %6.1f us cold\n", nt, msb[0], msb[1]);
+    }
   }
   return 0;
 }
