@@ -216,6 +216,9 @@ struct Builder {
   hipStream_t s;
   int64_t nparams = 0;
   std::vector<void*> temps;
+  bool x3 = false;                                         // LDMSEG_BF16X3 handle: every GEMM weight matrix becomes hi | lo planes at finish()
+  std::vector<std::pair<void*, size_t>> x3_w;              // (packed fp32 matrix, floats)
+  void weights(void* w, size_t nfloats) { if (x3 && dt == DT_F32) x3_w.emplace_back(w, nfloats); }
 
   int f32_copy(const std::string& key, int64_t n, float** out, int64_t pad_to = 0) {
     const float* src;
@@ -250,6 +253,7 @@ struct Builder {
     out->cout = Co;
     TRY(arena->alloc(&out->w, (size_t)Npad * k * k * cin_pad * esize(dt)));
     TRY(launch_repack_conv(w, out->w, Co, Ci, k, k, Npad, cin_pad, dt, s));
+    weights(out->w, (size_t)Npad * k * k * cin_pad);
     if (cm && k == 3 && cin_pad % bke(dt) == 0 && dt == DT_BF16 && Npad % 160 == 0) {
       TRY(arena->alloc(&out->w_cm, (size_t)Npad * k * k * cin_pad * esize(dt)));
       TRY(launch_repack_conv(w, out->w_cm, Co, Ci, k, k, Npad, cin_pad, dt, s, bke(dt)));
@@ -273,6 +277,9 @@ struct Builder {
     return 0;
   }
   int finish() {
+    // (after every row sum / bias that is computed FROM the packed matrices: the folded-LayerNorm c1 vectors)
+    for (const auto& e : x3_w) TRY(launch_split_planes(e.first, e.second, s));
+    x3_w.clear();
     HIP_TRY(hipStreamSynchronize(s));
     for (void* p : temps) (void)hipFree(p);
     temps.clear();
@@ -330,7 +337,7 @@ struct Exec {
     ProfScope ps(0, s, flops, bytes, dry(), label);
     if (dry()) return 0;
     TRY(ws_ok());
-    p.x3 = (dt == DT_F32) ? x3 : 0;
+    p.x3 = (dt == DT_F32) ? ((p.w_dynamic && x3) ? 1 : x3) : 0;      // (W = an activation tensor: split in the K loop)
     return launch_igemm(p, dt, s);
   }
 
@@ -618,6 +625,7 @@ int build_transformer(Builder& b, const std::string& p, int C, TransformerW* t) 
     ConvW& q = t->qkv;
     q.N = 3 * C; q.n_valid = 3 * C; q.cin_pad = C; q.taps = 1; q.cout = 3 * C;
     TRY(b.arena->alloc(&q.w, (size_t)3 * C * C * esize(dt)));
+    b.weights(q.w, (size_t)3 * C * C);
     std::vector<int> ident(C);
     for (int r = 0; r < C; ++r) ident[r] = r;
     int* dident;
@@ -660,6 +668,7 @@ int build_transformer(Builder& b, const std::string& p, int C, TransformerW* t) 
     TRY(b.wm->get(tb + "ff.net.0.proj.bias", N, &bias));
     // norm3 (LayerNorm) folded in: W' = gamma (.) W in the packed row order, c1 = rowsum(W'), bias = W beta + b
     TRY(b.arena->alloc(&f.w, (size_t)N * C * esize(dt)));
+    b.weights(f.w, (size_t)N * C);
     TRY(launch_repack_rows_scaled(w, f.w, dmap, N, C, t->ln3.g, dt, b.s));
     void* tmp;
     HIP_TRY(hipMalloc(&tmp, (size_t)N * C * sizeof(float)));
@@ -722,6 +731,7 @@ int build_transformer(Builder& b, const std::string& p, int C, TransformerW* t) 
 int unet_build(ldmseg_unet* u, const WeightMap& wm) {
   hipStream_t s = nullptr;
   Builder b{&u->arena, &wm, u->dt, s};
+  b.x3 = u->x3;
   const int cp = bke(u->dt);
   if (u->cfg.in_channels > cp) return fail(LDMSEG_E_ARG, "in_channels too large");
   TRY(b.conv("conv_in", kBlockOut[0], u->cfg.in_channels, 3, cp, &u->conv_in));
@@ -958,7 +968,7 @@ int unet_forward_impl(ldmseg_unet* u, const float* a, int Ca, const float* b, in
   ex.attn_fp8_min_tokens = u->attn_fp8_min_tokens;
   ex.gn_sync = u->gn_sync;
   ex.cf_sync = u->cf_sync;
-  ex.x3 = u->x3 ? 1 : 0;
+  ex.x3 = u->x3 ? 2 : 0;          // (2: the handle's weights are hi | lo planes, Builder::finish)
   ex.gn_poll_us = u->gn_backoff_calls > 0 ? 2 : -1;
   const int dt = u->dt;
 
@@ -1167,6 +1177,7 @@ int vae_build(ldmseg_vae* v, const WeightMap& wm) {
   const ldmseg_vae_cfg& c = v->cfg;
   const int dt = v->dt;
   Builder b{&v->arena, &wm, dt, s};
+  b.x3 = v->x3;
   if (c.in_channels > bke(dt) || c.latent_channels > bke(dt)) return fail(LDMSEG_E_ARG, "too many boundary channels");
   if (c.int_channels % 64 || c.upscale_channels % 64 || c.num_upscalers < 1 || c.num_upscalers > 4)
     return fail(LDMSEG_E_ARG, "unsupported seg-VAE configuration");
@@ -1198,6 +1209,7 @@ int vae_build(ldmseg_vae* v, const WeightMap& wm) {
     t.N = 4 * Co; t.n_valid = 4 * Co; t.cin_pad = cin; t.taps = 1; t.cout = Co;
     TRY(v->arena.alloc(&t.w, (size_t)4 * Co * cin * esize(dt)));
     TRY(launch_repack_convt2(w, t.w, cin, Co, dt, s));
+    b.weights(t.w, (size_t)4 * Co * cin);
     void* pb;
     TRY(v->arena.alloc(&pb, (size_t)4 * Co * sizeof(float)));
     for (int q = 0; q < 4; ++q)
@@ -1232,7 +1244,7 @@ int vae_decode_impl(ldmseg_vae* v, const float* z, float z_scale, int B, int L, 
   Exec ex{ws, v->dt, B, s};
   ex.gn_sync = v->gn_sync;
   ex.cf_sync = v->cf_sync;
-  ex.x3 = v->x3 ? 1 : 0;
+  ex.x3 = v->x3 ? 2 : 0;
   const int dt = v->dt;
   const ldmseg_vae_cfg& c = v->cfg;
   Act zin = ex.new_act(bke(dt), L, L, true);
@@ -1301,7 +1313,7 @@ int vae_encode_impl(ldmseg_vae* v, const float* x, float mul, float add, int B, 
   Exec ex{ws, v->dt, B, s};
   ex.gn_sync = v->gn_sync;
   ex.cf_sync = v->cf_sync;
-  ex.x3 = v->x3 ? 1 : 0;
+  ex.x3 = v->x3 ? 2 : 0;
   const int dt = v->dt;
   const ldmseg_vae_cfg& c = v->cfg;
   Act xin = ex.new_act(bke(dt), H, H, true);
@@ -1364,6 +1376,7 @@ constexpr int kKLMid = 512;
 int klenc_build(ldmseg_vae_image* v, const WeightMap& wm) {
   hipStream_t s = nullptr;
   Builder b{&v->arena, &wm, v->dt, s};
+  b.x3 = v->x3;
   const int cp = bke(v->dt);
   TRY(b.conv("encoder.conv_in", kKLCh[0], 3, 3, cp, &v->conv_in));
   int cin = kKLCh[0], dummy = 0;
@@ -1444,6 +1457,7 @@ int klenc_attention(Exec& ex, const ldmseg_vae_image* v, const Act& x, Act* out)
       IgemmParams p;                                   // S = Q_b K_b^T
       p.src0 = (const char*)q.p + off; p.C0 = C; p.B = 1; p.Hi = p.Ho = N; p.Wi = p.Wo = 1;
       p.M = N; p.N = N; p.n_valid = N; p.W = (const char*)k.p + off; p.out = S; p.ldo = N; p.epi = EPI_ROWS_F32;
+      p.w_dynamic = 1;
       TRY(ex.igemm(p));
     }
     {
@@ -1454,12 +1468,14 @@ int klenc_attention(Exec& ex, const ldmseg_vae_image* v, const Act& x, Act* out)
       IgemmParams p;                                   // V_b^T [C][N] = W_v X_b^T
       p.src0 = v->wv; p.C0 = C; p.B = 1; p.Hi = p.Ho = C; p.Wi = p.Wo = 1;
       p.M = C; p.N = N; p.n_valid = N; p.W = (const char*)n.p + off; p.out = Vt; p.ldo = N;
+      p.w_dynamic = 1;
       TRY(ex.igemm(p));
     }
     {
       IgemmParams p;                                   // O_b = P_b V_b + b_v
       p.src0 = P; p.C0 = N; p.B = 1; p.Hi = p.Ho = N; p.Wi = p.Wo = 1;
       p.M = N; p.N = C; p.n_valid = C; p.W = Vt; p.bias = v->bv; p.out = (char*)att.p + off; p.ldo = C;
+      p.w_dynamic = 1;
       TRY(ex.igemm(p));
     }
   }
@@ -1475,7 +1491,7 @@ int klenc_encode_impl(ldmseg_vae_image* v, const float* x, float mul, float add,
   Exec ex{ws, v->dt, B, s};
   ex.gn_sync = v->gn_sync;
   ex.cf_sync = v->cf_sync;
-  ex.x3 = v->x3 ? 1 : 0;
+  ex.x3 = v->x3 ? 2 : 0;
   const int dt = v->dt;
   Act xin = ex.new_act(bke(dt), H, W, true);
   {

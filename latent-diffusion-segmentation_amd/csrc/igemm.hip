@@ -948,7 +948,12 @@ __global__ __launch_bounds__((WAVES_M * WAVES_N + LDR) * 64, (WAVES_M * WAVES_N 
 #pragma unroll
           for (int a = 0; a < NF; ++a) {
             uint4 wh, wl;
-            split(*(const uint4*)(ws + a * 16 * kRowBytes + fr_c0), *(const uint4*)(ws + a * 16 * kRowBytes + fr_c1), wh, wl);
+            if (p.x3 == 2) {            // round 6: the weights were split at create time (launch_split_planes): chunk lg = hi, chunk lg + 4 = lo
+              wh = *(const uint4*)(ws + a * 16 * kRowBytes + fr_c0);
+              wl = *(const uint4*)(ws + a * 16 * kRowBytes + fr_c1);
+            } else {
+              split(*(const uint4*)(ws + a * 16 * kRowBytes + fr_c0), *(const uint4*)(ws + a * 16 * kRowBytes + fr_c1), wh, wl);
+            }
             // small terms first; consecutive MFMAs go to different accumulators
 #pragma unroll
             for (int b = 0; b < MF; ++b)
@@ -1660,6 +1665,42 @@ __global__ void pack_up4_kernel(const float* __restrict__ w, T* __restrict__ out
   }
 }
 }  // namespace
+namespace {
+// fp32 [rows][K] (K a multiple of 32) -> the same bytes as split-bf16 planes, in place: every 128-byte K tile (32 floats) becomes
+// [hi: 4 chunks of 8 bf16 | lo: 4 chunks of 8 bf16] with hi = bf16(w), lo = bf16(w - hi) - exactly what the x3 K loop computes per
+// fragment and tile - and chunk c holding k = 4c .. 4c+3, 16+4c .. 16+4c+3: the k set lane group c reads from an fp32 X tile (its
+// chunks c and c + 4), so both MFMA operands see the same contraction order.  One thread per tile.
+__global__ __launch_bounds__(256) void split_planes_kernel(float* __restrict__ w, size_t ntiles) {
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= ntiles) return;
+  f32x4* p = (f32x4*)(w + t * 32);
+  f32x4 f[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) f[i] = p[i];
+  u32x4 hi[4], lo[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float v[8] = {f[c][0], f[c][1], f[c][2], f[c][3], f[c + 4][0], f[c + 4][1], f[c + 4][2], f[c + 4][3]};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned h = pack_bf16x2(v[2 * i], v[2 * i + 1]);
+      const float r0 = v[2 * i] - bits_f32(h << 16), r1 = v[2 * i + 1] - bits_f32(h & 0xffff0000u);
+      hi[c][i] = h;
+      lo[c][i] = pack_bf16x2(r0, r1);
+    }
+  }
+  u32x4* q = (u32x4*)p;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { q[c] = hi[c]; q[c + 4] = lo[c]; }
+}
+}  // namespace
+int launch_split_planes(void* w, size_t nfloats, hipStream_t s) {
+  if (nfloats % 32 != 0) return -2;
+  const size_t ntiles = nfloats / 32;
+  if (!ntiles) return 0;
+  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((ntiles + 255) / 256)), dim3(256), 0, s, (float*)w, ntiles);
+  return hipGetLastError() == hipSuccess ? 0 : -3;
+}
 int launch_pack_up4(const float* w, void* out, int Co, int Ci, int Npad, int Cipad, int dtype, hipStream_t s) {
   const size_t total = (size_t)16 * Npad * Cipad;
   const size_t blocks = (total + 255) / 256;

@@ -101,7 +101,9 @@ struct IgemmParams {
   // set by the launcher: divisions the kernels need (by Ho*Wo, Wo, the number of n tiles / tiles / K slices, K tiles per tap)
   FastDiv fd_hwo, fd_wo, fd_nt, fd_ntiles, fd_nsplit, fd_tpt, fd_mphase;
   int x3 = 0;                    // fp32 launches only: split-bf16 arithmetic (hi + lo, three bf16 MFMAs per product block) instead of
-                                 // the exact fp32 MFMA - compute_dtype "bf16x3" of the handles
+                                 // the exact fp32 MFMA - compute_dtype "bf16x3" of the handles.  2 (round 6): W already holds the
+                                 // hi | lo planes (launch_split_planes at create time): no weight split in the K loop
+  int w_dynamic = 0;             // host-side: W is an activation tensor of this call (image-VAE attention), never pre-split
   int dbg = 0;                   // ablation flags for profiling experiments (results are wrong when != 0)
   unsigned long long* ts = nullptr;   // LDMSEG_IGEMM_ABLATE builds: per-workgroup s_memtime stamps (wave 0)
 };
@@ -146,6 +148,8 @@ int igemm_get_xt_mode();
 // wcat [C][5C] fp32 = [Wp W2 | Wp], bcat [C] = bp + Wp b2 (wp [C][C], w2 [C][4C]; fp32 products, create time only)
 int launch_chain_weights(const float* wp, const float* w2, const float* b2, const float* bp, float* wcat, float* bcat, int C, hipStream_t s);
 int launch_vec_add(const float* a, const float* b, float* out, int n, hipStream_t s);
+// packed fp32 weights [rows][K] -> split-bf16 planes in place (IgemmParams::x3 == 2); nfloats a multiple of 32
+int launch_split_planes(void* w, size_t nfloats, hipStream_t s);
 int launch_concat_rows(const void* a, int K1, const void* b, int K2, void* out, int N, int dtype, hipStream_t s);
 void igemm_force_cfg(int cfg);   // tuning tool: >= 0 runs every launch with that entry of the instantiation list, -1 = off
 int igemm_get_dbg();       // current (policy << 8) | ablation flags

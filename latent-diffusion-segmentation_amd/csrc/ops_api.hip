@@ -398,8 +398,8 @@ static int op_igemm_impl(const float* x, const float* x2, const float* w, const 
                          int silu, int splits, int dtype, float* out, void* stream, int time_iters, float* us_per_launch) {
   hipStream_t s = (hipStream_t)stream;
   Temp t;
-  const int x3 = dtype == 2 ? 1 : 0;        // LDMSEG_BF16X3: fp32 storage, split-bf16 products
-  if (x3) dtype = DT_F32;
+  const int x3 = dtype == 2 ? 1 : (dtype == 3 ? 2 : 0);   // LDMSEG_BF16X3: fp32 storage, split-bf16 products; 3 = the same with the weights
+  if (x3) dtype = DT_F32;                                 // split into hi | lo planes up front, as the handles hold them (round 6)
   const int a = bke(dtype);
   const int c0 = rupi(Ci, a), c1 = Ci2 ? rupi(Ci2, a) : 0;
   if (Ci2 && (Ci % a)) return -2;
@@ -453,6 +453,7 @@ static int op_igemm_impl(const float* x, const float* x2, const float* w, const 
   p.rowbias = rowbias; p.rb_stride = Co;
   p.resid = rp; p.ldr = cout; p.out = op; p.ldo = cout; p.epi = epi; p.silu = silu;
   p.x3 = x3;
+  if (x3 == 2 && launch_split_planes(wp, (size_t)Np * k * k * ct, s)) return -3;
   if (up && k == 3 && stride == 1 && !Ci2 && !geglu && !resid && !rowbias && !silu && igemm_up4_ok(B, H, W, c0, Np, dtype) && Ci == c0) {
     // the engine's form of an upsampler conv: four 2x2 phase convs on the low-resolution map (IgemmParams::up4)
     void* w4 = t.get((size_t)16 * Np * c0 * es(dtype));
@@ -621,7 +622,7 @@ int ldmseg_op_ln_linear(const float* x, const float* gamma, const float* beta, c
                         int N, float eps, int geglu, int dtype, float* out, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   Temp t;
-  const int x3 = dtype == 2 ? 1 : 0;        // LDMSEG_BF16X3
+  const int x3 = dtype == 2 ? 1 : (dtype == 3 ? 2 : 0);   // LDMSEG_BF16X3 (3: weights pre-split into planes)
   if (x3) dtype = DT_F32;
   if (K % bke(dtype)) return -2;
   void* xp = t.get((size_t)M * K * es(dtype));
@@ -656,6 +657,7 @@ int ldmseg_op_ln_linear(const float* x, const float* gamma, const float* beta, c
   p.M = M; p.N = Np; p.n_valid = nout; p.W = wp; p.bias = c2; p.rowstats = stats; p.c1 = c1;
   p.out = op; p.ldo = nout; p.epi = epi;
   p.x3 = x3;
+  if (x3 == 2 && launch_split_planes(wp, (size_t)Np * K, s)) return -3;      // (c1 / c2 above were taken from the fp32 matrix)
   const int sp = igemm_plan_splits(p, dtype);
   if (sp > 1) { p.splits = sp; p.partial = (float*)t.get((size_t)sp * M * Np * sizeof(float)); }
   const int r = launch_igemm(p, dtype, s);

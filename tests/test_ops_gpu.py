@@ -1269,6 +1269,15 @@ def test_split_bf16_gemm_vs_fp32_reference(L, case):
     assert name.startswith("igemm<f32,") and ",0,0" in name, name          # a plain-K-loop fp32 instantiation
     e = rel_err(out, ref)
     assert e < 1e-4, (case, name, e)
+    # round 6: dtype 3 = the same arithmetic with the weights split into hi | lo planes once, up front (what a bf16x3 handle holds):
+    # the planes are exactly the values the K loop would have computed, so the result must not move a bit
+    out3 = torch.empty(ref.shape, device="cuda")
+    r = L.lib().ldmseg_op_igemm(P(dx), P(dx2), P(dw), P(db), P(dres), P(drb), B, Ci, Ci2, H, H, Co, k, stride, up, geglu,
+                                0, 0, 3, P(out3), None)
+    assert r == 0, L.lib().ldmseg_last_error()
+    torch.cuda.synchronize()
+    assert L.igemm_last_kernel() == name
+    assert torch.equal(out3, out), case
 
 
 @pytest.mark.parametrize("M,K,N,geglu", [(2048, 640, 1920, 0), (512, 1280, 10240, 1), (4096, 320, 960, 0)])
@@ -1291,6 +1300,10 @@ def test_split_bf16_layernorm_folded_gemm(L, M, K, N, geglu):
     name = L.igemm_last_kernel()
     assert ",ln" in name and name.startswith("igemm<f32,"), name
     assert rel_err(out, y) < 2e-4, name
+    out3 = torch.empty(y.shape, device="cuda")             # weights pre-split into planes (dtype 3): bit-identical
+    assert L.lib().ldmseg_op_ln_linear(P(dx), P(dg), P(db), P(dw), P(dbias), M, K, N, 1e-5, geglu, 3, P(out3), None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out3, out), name
 
 
 @pytest.mark.parametrize("B,N,Cc", [(2, 4096, 320), (2, 1024, 640), (8, 256, 1280), (3, 64, 1280), (1, 200, 320), (1, 33, 640)])
